@@ -1,0 +1,121 @@
+/*
+ * include/tsp2opt.h -- C ABI of libtsp2opt_hip.so
+ *
+ * MI355X (gfx950) implementation of ML4TSPBench's batched best-improvement 2-opt local search.
+ * The calling convention follows the reference's own native-extension convention
+ * (search/c_mcts/mcts.cpp:8-36 + search/c_mcts/__init__.py:11-29): extern "C", raw pointers and
+ * integers, loaded with ctypes.CDLL, argtypes/restype declared on the Python side.
+ * Unlike that code the library never returns library-owned memory: every buffer belongs to the
+ * caller (PyTorch-ROCm tensors in practice) and all pointers except `hip_stream` are DEVICE
+ * pointers of contiguous arrays on `device`.
+ *
+ * Every entry point returns 0 on success or a negative TSP2OPT_E_* code; the message for the
+ * calling thread's last failure is tsp2opt_last_error().  No C++ exception crosses the ABI.
+ */
+#ifndef TSP2OPT_H_
+#define TSP2OPT_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSP2OPT_VERSION 100            /* 0.1.0 */
+
+#define TSP2OPT_DTYPE_F32 0            /* arithmetic in float, like the plugin with fp32 points */
+#define TSP2OPT_DTYPE_F64 1            /* arithmetic in double, like tsp_2opt (two_opt.py:67)   */
+
+/* return codes */
+#define TSP2OPT_OK              0
+#define TSP2OPT_E_ARG         (-1)     /* bad argument (null pointer, n < 1, sizes inconsistent) */
+#define TSP2OPT_E_UNSUPPORTED (-2)     /* n above the supported maximum                          */
+#define TSP2OPT_E_WORKSPACE   (-3)     /* workspace_bytes too small                              */
+#define TSP2OPT_E_HIP         (-4)     /* a HIP runtime call failed (message has the HIP error)  */
+
+/* per-tour status bits written to `status_out` */
+#define TSP2OPT_ST_BAD_INDEX    1      /* a tour entry is outside [0, n): tour left untouched    */
+#define TSP2OPT_ST_NOT_CLOSED   2      /* tour[n] != tour[0]: tour left untouched                */
+#define TSP2OPT_ST_NONFINITE    4      /* instance has a NaN/Inf coordinate: 0 iterations, like
+                                          the reference whose NaN minimum ends the loop          */
+#define TSP2OPT_ST_RANGE        8      /* |coordinate| > 1e150: outside the supported range      */
+#define TSP2OPT_ST_CAPPED      16      /* stopped by max_iterations                              */
+#define TSP2OPT_ST_TIME        32      /* stopped by time_limit_s                                */
+
+/* Largest n the kernels accept (tour positions are held as 16-bit values on chip). */
+#define TSP2OPT_MAX_N 65535
+
+/*
+ * tsp2opt_solve -- replaces the hot loop of
+ *   batched_two_opt_torch            search/two_opt.py:21-48           (group_size = batch rows)
+ *   ML4TSPNARTwoOpt._local_search    ml4tsp-library/ml4tsp/nar/local_search/two_opt.py:34-65
+ *   ML4TSPNARLocalSearch.local_search's per-tour Python loop
+ *                                    ml4tsp-library/ml4tsp/nar/local_search/base.py:58-64
+ * for ALL tours of a batch in one call: the whole improvement loop runs on the device, no
+ * per-iteration host round trip.
+ *
+ *   points   (num_instances, n, 2) float or double, node order, row-major
+ *   tours    (num_tours, n+1) int64, tour[n] == tour[0]; UPDATED IN PLACE (pass a clone: the
+ *            reference never mutates its input, two_opt.py:12)
+ *   iters_out  (num_tours) int32 or NULL: the reference's `iterator` of the call the tour belongs
+ *            to (its own count when group_size == 1, the group's shared count otherwise)
+ *   sweeps_out (num_tours) int32 or NULL: full (i,j) sweeps the reference algorithm performs for
+ *            that result: iterator+1 when it stopped on convergence, iterator when capped
+ *   lengths_out (num_tours) double or NULL: closed-tour length of the result, summed in double
+ *   status_out (num_tours) int32 or NULL: TSP2OPT_ST_* bits
+ *   tours_per_instance  tour k belongs to instance k / tours_per_instance
+ *            (base.py:61: idx // per_tours_num // per_heatmap_num)
+ *   group_size  1: every tour stops on its own minimum (the plugin, two_opt.py:33 batch_size = 1)
+ *               P: consecutive P tours stop together on the minimum over the whole group
+ *                  (search/two_opt.py:35,40); needs tours_per_instance % P == 0, num_tours % P == 0
+ *   max_iterations  two_opt.py:47 / max_iterations_2opt (default 5000 in both front ends)
+ *   time_limit_s    <= 0: none ("auto"); > 0: per-tour wall-clock limit checked once per iteration
+ *                   (plugin two_opt.py:63-65); only honoured when group_size == 1
+ *   dtype     TSP2OPT_DTYPE_F32 / _F64: dtype of `points` AND of the arithmetic
+ *   device    HIP device ordinal that owns the buffers
+ *   workspace / workspace_bytes  device scratch of at least tsp2opt_workspace_bytes(...) bytes,
+ *            256-byte aligned; NULL: the library allocates and frees it on `hip_stream`
+ *   hip_stream  hipStream_t to enqueue on (torch.cuda.current_stream(device).cuda_stream); the
+ *            call is asynchronous with respect to the host
+ *
+ * Results: bit-identical tours to the reference algorithm evaluated with IEEE-754 correctly
+ * rounded +,-,*,sqrt in `dtype` and first-flat-index argmin tie-breaking.
+ */
+int tsp2opt_solve(const void* points, int64_t* tours, int32_t* iters_out, int32_t* sweeps_out,
+                  double* lengths_out, int32_t* status_out, int64_t num_tours, int32_t n,
+                  int32_t tours_per_instance, int32_t group_size, int32_t max_iterations,
+                  double time_limit_s, int32_t dtype, int32_t device, void* workspace,
+                  int64_t workspace_bytes, void* hip_stream);
+
+/* Bytes of device scratch tsp2opt_solve needs for this problem size (> 0), or a negative code. */
+int64_t tsp2opt_workspace_bytes(int64_t num_tours, int32_t n, int32_t group_size);
+
+/*
+ * tsp2opt_tour_lengths -- closed-tour length of every tour, summed in double from `dtype`
+ * coordinates.  Replaces the per-edge Python loop of TSPEvaluator.evaluate
+ * (utils/evaluator.py:5-13) for a whole batch; used for the final "tours + lengths" gather.
+ */
+int tsp2opt_tour_lengths(const void* points, const int64_t* tours, double* lengths_out,
+                         int64_t num_tours, int32_t n, int32_t tours_per_instance, int32_t dtype,
+                         int32_t device, void* hip_stream);
+
+/*
+ * tsp2opt_sqrt_check -- numerics self-test used by the GPU test-suite: out[k] = sqrt(in[k])
+ * computed with the exact device routine the delta evaluation uses (dtype as above).  Lets the
+ * tests prove 0-ulp agreement with the host's correctly rounded sqrt (SURVEY.md hard part b).
+ */
+int tsp2opt_sqrt_check(const void* in, void* out, int64_t count, int32_t dtype, int32_t device,
+                       void* hip_stream);
+
+/* Kernel variant / launch geometry the library would pick for n (for logs and tests).
+ * out[0]=threads per workgroup, out[1]=fast-path class (0: exact-only kernel), out[2]=LDS bytes,
+ * out[3]=row segments, out[4]=diagonal groups, out[5]=macro steps, out[6]=resident workgroups/CU */
+int tsp2opt_plan(int32_t n, int32_t dtype, int32_t device, int32_t* out7);
+
+const char* tsp2opt_last_error(void);
+int tsp2opt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSP2OPT_H_ */

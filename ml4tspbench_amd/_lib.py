@@ -1,0 +1,86 @@
+"""ctypes binding of libtsp2opt_hip.so (include/tsp2opt.h).
+
+Follows the reference's own native-extension convention (search/c_mcts/__init__.py:11-29:
+ctypes.CDLL + argtypes/restype).  There is NO fallback: if the library or a GPU is missing the
+call fails loudly (the CPU oracle under oracle/ is test infrastructure and is never used here).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtsp2opt_hip.so")
+
+DTYPE_F32 = 0
+DTYPE_F64 = 1
+
+ST_BAD_INDEX = 1
+ST_NOT_CLOSED = 2
+ST_NONFINITE = 4
+ST_RANGE = 8
+ST_CAPPED = 16
+ST_TIME = 32
+
+MAX_N = 65535
+
+_lib = None
+
+# every symbol include/tsp2opt.h declares (tests/test_abi.py checks the list against the header)
+SYMBOLS = (
+    "tsp2opt_solve",
+    "tsp2opt_workspace_bytes",
+    "tsp2opt_tour_lengths",
+    "tsp2opt_sqrt_check",
+    "tsp2opt_plan",
+    "tsp2opt_last_error",
+    "tsp2opt_version",
+)
+
+
+class Tsp2optError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load the HIP library; raises if it has not been built (python -m ml4tspbench_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Tsp2optError(
+            f"{LIB_PATH} is missing: build it with `python -m ml4tspbench_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+    L.tsp2opt_solve.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f64, i32, i32,
+                                vp, i64, vp]
+    L.tsp2opt_solve.restype = ctypes.c_int
+    L.tsp2opt_workspace_bytes.argtypes = [i64, i32, i32]
+    L.tsp2opt_workspace_bytes.restype = i64
+    L.tsp2opt_tour_lengths.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp]
+    L.tsp2opt_tour_lengths.restype = ctypes.c_int
+    L.tsp2opt_sqrt_check.argtypes = [vp, vp, i64, i32, i32, vp]
+    L.tsp2opt_sqrt_check.restype = ctypes.c_int
+    L.tsp2opt_plan.argtypes = [i32, i32, i32, ctypes.POINTER(i32)]
+    L.tsp2opt_plan.restype = ctypes.c_int
+    L.tsp2opt_last_error.argtypes = []
+    L.tsp2opt_last_error.restype = ctypes.c_char_p
+    L.tsp2opt_version.argtypes = []
+    L.tsp2opt_version.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc < 0:
+        msg = lib().tsp2opt_last_error()
+        raise Tsp2optError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def plan(n: int, dtype: int = DTYPE_F64, device: int = -1) -> dict:
+    out = (ctypes.c_int32 * 7)()
+    check(lib().tsp2opt_plan(n, dtype, device, out), "tsp2opt_plan")
+    keys = ("threads", "filter_class", "lds_bytes", "row_segments", "diag_groups", "macro_steps",
+            "workgroups_per_cu")
+    return dict(zip(keys, list(out)))

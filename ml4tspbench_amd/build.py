@@ -1,0 +1,40 @@
+"""Build libtsp2opt_hip.so in-tree with hipcc for gfx950 (MI355X).
+
+    python -m ml4tspbench_amd.build [--force]
+
+-ffp-contract=off is REQUIRED: the exact delta evaluation must round the two squares and their sum
+separately, like the reference's separate torch kernels (search/two_opt.py:27).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "tsp2opt.hip")
+HDR = os.path.join(ROOT, "include", "tsp2opt.h")
+LIB = os.path.join(HERE, "libtsp2opt_hip.so")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [
+    "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
+    "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+    "-I", os.path.join(ROOT, "include"),
+]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    newest = max(os.path.getmtime(SRC), os.path.getmtime(HDR), os.path.getmtime(__file__))
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
+        return LIB
+    cmd = [HIPCC, *FLAGS, "-o", LIB, SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,1095 @@
+// ml4tspbench_amd/csrc/tsp2opt.hip -- gfx950 kernels + C ABI of libtsp2opt_hip.so
+//
+// Batched best-improvement 2-opt local search, the whole improvement loop on the device.
+// Replaces (reference, read-only): search/two_opt.py:21-48 and
+// ml4tsp-library/ml4tsp/nar/local_search/two_opt.py:34-65 (+ the per-tour Python loop of
+// ml4tsp-library/ml4tsp/nar/local_search/base.py:58-64).  Design: DESIGN.md.
+//
+// One workgroup owns one tour.  Per iteration it must find the reference's argmin over all
+// position pairs (i, j >= i+2) of
+//     delta(i,j) = ((D(i,j) + D(i+1,j+1)) - D(i,i+1)) - D(j,j+1),   D = Euclidean distance
+// evaluated in the reference's dtype with IEEE-correct +,-,*,sqrt and no FMA, ties broken by the
+// lowest flat index i*N+j, then reverse tour[i+1..j].
+//
+// Hot loop ("filter sweep"): the pair triangle is re-indexed as CYCLIC DIAGONALS (r, (r+d) mod N),
+// d = 2..N/2, which is a rectangle (no triangle waste) and along which D(r+1,c+1) of one pair is
+// D(r,c) of the next, so each pair costs ONE distance.  A lane owns 4 adjacent diagonals and walks
+// rows in macro steps of 4 (16 pairs, 16 sqrt), with tour-ordered, centred and scaled fp32
+// coordinates staged in LDS in a 4-way interleaved layout (conflict-free ds_read_b64, uniform row
+// reads broadcast).  The fp32 value is only a FILTER with a proven error bound eps: every lane keeps
+// its best macro-step a1 and runner-up a2; after a workgroup min m, only macro steps with
+// a1 <= m + 2 eps can hold the true argmin and are re-evaluated EXACTLY (reference dtype, reference
+// operation order) by wave 0; if some lane's runner-up is also inside the window the workgroup
+// falls back to a full exact sweep for that iteration.  The result is bit-identical to evaluating
+// every pair exactly, at fp32 VALU cost.
+//
+// MFMA is deliberately not used: gather + sqrt + compare work, no dense contraction.
+//
+// Compile with -ffp-contract=off (see build.py); the exact path relies on separate mul and add.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "tsp2opt.h"
+
+#pragma clang fp contract(off)
+
+namespace t2o {
+
+// ------------------------------------------------------------------------------------------
+// constants shared by host and device
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxCand = 64;          // exact re-evaluation list (macro steps) per iteration
+constexpr int kMaxWaves = 16;         // 1024 threads
+constexpr int kModeIndep = 0;         // run from iteration 0 until the tour's own stop test
+constexpr int kModeForced = 1;        // continue to the group's iteration count (coupled mode)
+constexpr unsigned kNoMove = 0u;      // packed (i<<16|j) == 0 <=> flat argmin index 0 <=> no move
+
+struct Geo {                          // launch geometry of the filter sweep (host: make_plan)
+    int n;                            // nodes
+    int nt;                           // threads per workgroup
+    int qclass;                       // 0: exact-only kernel; else sub-array stride Q
+    int G;                            // lane groups of 4 diagonals
+    int NS;                           // row segments
+    int MS;                           // macro steps (4 rows) per segment
+    int xlds;                         // exact coordinates cached in LDS
+    float eps2;                       // 2*eps of the filter, in scaled units
+};
+
+struct Params {
+    const void* points;
+    int64_t* tours;
+    int32_t* iters;                   // INDEP: out.  FORCED: in (own count) / unchanged
+    int32_t* work_sweeps;             // sweeps actually executed (accumulated)
+    int32_t* status;
+    const int32_t* target;            // FORCED: per-group iteration count
+    int32_t* group_flag;              // FORCED: set when a tour is still active at the target
+    unsigned* queue;                  // tour queue head
+    int64_t num_tours;
+    int tpi;
+    int group_size;
+    int max_iter;
+    int mode;
+    long long time_limit_ticks;       // wall_clock64 ticks, 0 = none
+    Geo g;
+};
+
+struct Ctl {                          // LDS control block (first bytes of dynamic LDS)
+    double redd[kMaxWaves * 4];       // block reductions
+    double pE[kMaxWaves];
+    unsigned pIdx[kMaxWaves];
+    float wmin[kMaxWaves];
+    unsigned cand[kMaxCand];
+    unsigned ncand;
+    int ambiguous;
+    int tour_id;
+    int flags;
+    double bestE;
+    unsigned bestIdx;
+    unsigned pad;
+    double cx, cy, sc;
+};
+
+// ------------------------------------------------------------------------------------------
+// exact arithmetic in the reference's dtype (search/two_opt.py:27-32): separate sub, mul, add,
+// correctly rounded sqrt.  fp32 sqrt goes through the correctly rounded fp64 sqrt: rounding a
+// 53-bit correctly rounded root of a 24-bit value to 24 bits is itself correctly rounded.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sqrt_rn(double x) { return __builtin_sqrt(x); }
+__device__ __forceinline__ float sqrt_rn(float x) { return (float)__builtin_sqrt((double)x); }
+
+template <typename T>
+__device__ __forceinline__ T dist_exact(T ax, T ay, T bx, T by)
+{
+    T dx = ax - bx, dy = ay - by;
+    T sx = dx * dx;
+    T sy = dy * dy;
+    return sqrt_rn(sx + sy);
+}
+
+// fp32 filter distance: FMA and the raw 1-ulp v_sqrt_f32 are fine here, the error is budgeted.
+__device__ __forceinline__ float dist32(float2 a, float2 b)
+{
+    float dx = a.x - b.x, dy = a.y - b.y;
+    return __builtin_amdgcn_sqrtf(__builtin_fmaf(dy, dy, dx * dx));
+}
+
+__device__ __forceinline__ bool better(double e, unsigned idx, double be, unsigned bidx)
+{
+    return e < be || (e == be && idx < bidx);
+}
+
+__device__ __forceinline__ void wave_best(double& e, unsigned& idx)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double oe = __shfl_xor(e, off);
+        unsigned oi = __shfl_xor(idx, off);
+        if (better(oe, oi, e, idx)) { e = oe; idx = oi; }
+    }
+}
+
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS view of one tour
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct View {
+    Ctl* ctl;
+    uint16_t* tour;        // n+1 positions
+    float2* Pq;            // 4*Q filter coordinates, slot(w) = (w&3)*Q + (w>>2), w = window index
+    float* Eq;             // 4*Q filter edge lengths e[w] = |P[w] P[w+1]|
+    const T* X;            // exact coordinates, node order (LDS copy or global)
+};
+
+template <int Q>
+__device__ __forceinline__ int slot(int w) { return (w & 3) * Q + (w >> 2); }
+
+// exact delta of position pair (i, j), i + 2 <= j <= n-1, in the reference's operation order
+template <typename T>
+__device__ __forceinline__ double exact_delta(const View<T>& v, int i, int j)
+{
+    const int ti = v.tour[i], ti1 = v.tour[i + 1], tj = v.tour[j], tj1 = v.tour[j + 1];
+    const T xi = v.X[2 * ti], yi = v.X[2 * ti + 1];
+    const T xi1 = v.X[2 * ti1], yi1 = v.X[2 * ti1 + 1];
+    const T xj = v.X[2 * tj], yj = v.X[2 * tj + 1];
+    const T xj1 = v.X[2 * tj1], yj1 = v.X[2 * tj1 + 1];
+    const T a_ij = dist_exact(xi, yi, xj, yj);
+    const T a_i1j1 = dist_exact(xi1, yi1, xj1, yj1);
+    const T a_ii1 = dist_exact(xi, yi, xi1, yi1);
+    const T a_jj1 = dist_exact(xj, yj, xj1, yj1);
+    const T d = ((a_ij + a_i1j1) - a_ii1) - a_jj1;      // two_opt.py:32, left to right
+    return (double)d;
+}
+
+// Full exact sweep by the whole workgroup (fallback of the filter, and the only sweep of the
+// exact-only kernel).  Thread-local scan order is ascending (i, j), so strict '<' keeps the
+// lowest flat index; the cross-thread reduction is lexicographic on (delta, index).
+template <typename T>
+__device__ void exact_sweep(const View<T>& v, int n, int tid, int nt, double& e, unsigned& idx)
+{
+    e = 0.0;
+    idx = kNoMove;
+    for (int i = tid; i + 2 <= n - 1; i += nt) {
+        const int ti = v.tour[i], ti1 = v.tour[i + 1];
+        const T xi = v.X[2 * ti], yi = v.X[2 * ti + 1];
+        const T xi1 = v.X[2 * ti1], yi1 = v.X[2 * ti1 + 1];
+        const T a_ii1 = dist_exact(xi, yi, xi1, yi1);
+        int tj = v.tour[i + 2];
+        T xj = v.X[2 * tj], yj = v.X[2 * tj + 1];
+        for (int j = i + 2; j <= n - 1; ++j) {
+            const int tj1 = v.tour[j + 1];
+            const T xj1 = v.X[2 * tj1], yj1 = v.X[2 * tj1 + 1];
+            const T a_ij = dist_exact(xi, yi, xj, yj);
+            const T a_i1j1 = dist_exact(xi1, yi1, xj1, yj1);
+            const T a_jj1 = dist_exact(xj, yj, xj1, yj1);
+            const double d = (double)(((a_ij + a_i1j1) - a_ii1) - a_jj1);
+            if (d < e) { e = d; idx = ((unsigned)i << 16) | (unsigned)j; }
+            xj = xj1; yj = yj1;
+        }
+    }
+}
+
+// workgroup-wide lexicographic min of (e, idx); result valid in every thread
+__device__ void block_best(Ctl* ctl, int tid, int nt, double& e, unsigned& idx)
+{
+    wave_best(e, idx);
+    const int nw = nt >> 6;
+    if (nw == 1) return;
+    if ((tid & 63) == 0) { ctl->pE[tid >> 6] = e; ctl->pIdx[tid >> 6] = idx; }
+    __syncthreads();
+    e = ctl->pE[0];
+    idx = ctl->pIdx[0];
+    for (int w = 1; w < nw; ++w) {
+        const double oe = ctl->pE[w];
+        const unsigned oi = ctl->pIdx[w];
+        if (better(oe, oi, e, idx)) { e = oe; idx = oi; }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// filter sweep
+// ------------------------------------------------------------------------------------------
+template <int Q>
+__device__ __forceinline__ void load_block(const float2* Pq, const float* Eq, int b,
+                                           float2 (&C)[4], float (&E)[4])
+{
+    // C[u] = P[4b+2+u], E[u] = e[4b+1+u]
+    C[0] = Pq[2 * Q + b];
+    C[1] = Pq[3 * Q + b];
+    C[2] = Pq[b + 1];
+    C[3] = Pq[Q + b + 1];
+    E[0] = Eq[Q + b];
+    E[1] = Eq[2 * Q + b];
+    E[2] = Eq[3 * Q + b];
+    E[3] = Eq[b + 1];
+}
+
+// One macro step: rows r0..r0+3 (r0 = 4*rowIdx) x diagonals of this lane, 16 pairs.
+//   Cold[u] = P[c0+u], Cnew[u] = P[c0+4+u], Eold[u] = e[c0-1+u], Enew[u] = e[c0+3+u],
+//   Dc[q] = D(r0, c0+q) on entry and D(r0+4, c0+4+q) on exit, c0 = r0 + 2 + 4*g.
+template <int Q>
+__device__ __forceinline__ float macro_step(const float2* Pq, const float* Eq, int rowIdx,
+                                            int colIdx, const float2 (&Cold)[4],
+                                            float2 (&Cnew)[4], const float (&Eold)[4],
+                                            float (&Enew)[4], float (&Dc)[4])
+{
+    load_block<Q>(Pq, Eq, colIdx, Cnew, Enew);
+    float2 R[4];
+    float er[4];
+    R[0] = Pq[Q + rowIdx];          // P[r0+1]
+    R[1] = Pq[2 * Q + rowIdx];      // P[r0+2]
+    R[2] = Pq[3 * Q + rowIdx];      // P[r0+3]
+    R[3] = Pq[rowIdx + 1];          // P[r0+4]
+    er[0] = Eq[rowIdx];             // e[r0]
+    er[1] = Eq[Q + rowIdx];
+    er[2] = Eq[2 * Q + rowIdx];
+    er[3] = Eq[3 * Q + rowIdx];
+    float mm = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float t[4], Dn[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int vp = a + q + 1;                   // column point c0 + vp
+            const float2 C = vp < 4 ? Cold[vp] : Cnew[vp - 4];
+            Dn[q] = dist32(R[a], C);                    // D(r0+a+1, c0+a+q+1)
+            const int ve = a + q;                       // column edge c0 + ve
+            const float ec = ve < 3 ? Eold[ve + 1] : Enew[ve - 3];
+            t[q] = (Dc[q] + Dn[q]) - ec;
+        }
+        const float rm = fminf(fminf(t[0], t[1]), fminf(t[2], t[3])) - er[a];
+        mm = fminf(mm, rm);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Dc[q] = Dn[q];
+    }
+    return mm;
+}
+
+__device__ __forceinline__ void track(float mm, unsigned id, float& a1, float& a2, unsigned& chunk)
+{
+    a2 = __builtin_amdgcn_fmed3f(a1, mm, a2);   // runner-up (a1 <= a2 invariant)
+    chunk = mm < a1 ? id : chunk;
+    a1 = fminf(a1, mm);
+}
+
+template <int Q>
+__device__ __forceinline__ void filter_sweep(const float2* Pq, const float* Eq, const Geo& g,
+                                             int tid, float& a1, float& a2, unsigned& chunk)
+{
+    a1 = INFINITY;
+    a2 = INFINITY;
+    chunk = 0;
+    const int units = g.G * g.NS;
+    for (int u = tid; u < units; u += g.nt) {
+        const int gi = u % g.G, s = u / g.G;
+        int rowIdx = s * g.MS;
+        int colIdx = rowIdx + gi + 1;
+        float2 C0[4], C1[4];
+        float E0[4], E1[4], Dc[4];
+        load_block<Q>(Pq, Eq, colIdx - 1, C0, E0);
+        const float2 A0 = Pq[rowIdx];                   // P[r0]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Dc[q] = dist32(A0, C0[q]);
+        unsigned id = (unsigned)u * (unsigned)g.MS;
+        int m = 0;
+        for (; m + 1 < g.MS; m += 2) {
+            float mm = macro_step<Q>(Pq, Eq, rowIdx, colIdx, C0, C1, E0, E1, Dc);
+            track(mm, id, a1, a2, chunk);
+            mm = macro_step<Q>(Pq, Eq, rowIdx + 1, colIdx + 1, C1, C0, E1, E0, Dc);
+            track(mm, id + 1, a1, a2, chunk);
+            rowIdx += 2; colIdx += 2; id += 2;
+        }
+        if (m < g.MS) {
+            const float mm = macro_step<Q>(Pq, Eq, rowIdx, colIdx, C0, C1, E0, E1, Dc);
+            track(mm, id, a1, a2, chunk);
+        }
+    }
+}
+
+// exact value of pair `pr` (0..15) of macro step `id`; returns packed index
+template <typename T>
+__device__ __forceinline__ void eval_chunk_pair(const View<T>& v, const Geo& g, unsigned id, int pr,
+                                                double& e, unsigned& idx)
+{
+    const int u = (int)(id / (unsigned)g.MS), m = (int)(id % (unsigned)g.MS);
+    const int gi = u % g.G, s = u / g.G;
+    const int r0 = 4 * (s * g.MS + m);
+    const int c0 = r0 + 2 + 4 * gi;
+    const int a = pr >> 2, q = pr & 3;
+    const int r = (r0 + a) % g.n, c = (c0 + a + q) % g.n;
+    const int i = r < c ? r : c, j = r < c ? c : r;
+    e = exact_delta(v, i, j);
+    idx = ((unsigned)i << 16) | (unsigned)j;
+}
+
+// One full argmin (the reference's per-tour torch.min / torch.argmin, two_opt.py:35-38).
+// Returns in every thread: e = min(0, min valid delta), idx = packed (i,j) or kNoMove.
+template <typename T, int Q>
+__device__ void find_best(const View<T>& v, const Geo& g, int tid, double& e, unsigned& idx)
+{
+    Ctl* ctl = v.ctl;
+    if constexpr (Q == 0) {
+        exact_sweep(v, g.n, tid, g.nt, e, idx);
+        block_best(ctl, tid, g.nt, e, idx);
+        return;
+    } else {
+        float a1, a2;
+        unsigned chunk;
+        filter_sweep<Q>(v.Pq, v.Eq, g, tid, a1, a2, chunk);
+        const float wm = wave_min(a1);
+        const int nw = g.nt >> 6;
+        if ((tid & 63) == 0) ctl->wmin[tid >> 6] = wm;
+        __syncthreads();
+        float m = ctl->wmin[0];
+        for (int w = 1; w < nw; ++w) m = fminf(m, ctl->wmin[w]);
+        const float thr = m + g.eps2;
+        if (a1 <= thr) {
+            const unsigned sl = atomicAdd(&ctl->ncand, 1u);
+            if (sl < (unsigned)kMaxCand) ctl->cand[sl] = chunk;
+        }
+        if (a2 <= thr) ctl->ambiguous = 1;
+        __syncthreads();
+        const unsigned nc = ctl->ncand;
+        const bool slow = ctl->ambiguous != 0 || nc > (unsigned)kMaxCand;
+        if (slow) {
+            exact_sweep(v, g.n, tid, g.nt, e, idx);
+            block_best(ctl, tid, g.nt, e, idx);     // ends with a barrier when nw > 1
+            if (nw == 1) __syncthreads();
+            if (tid == 0) { ctl->ncand = 0; ctl->ambiguous = 0; }
+            return;
+        }
+        if (tid < 64) {
+            e = 0.0;
+            idx = kNoMove;
+            if (tid == 0) {     // the pair (0, n-1): cyclically adjacent, not on any walked diagonal
+                const double d = exact_delta(v, 0, g.n - 1);
+                if (d < e) { e = d; idx = (unsigned)(g.n - 1); }
+            }
+            for (unsigned base = 0; base < nc; base += 4) {
+                const unsigned ci = base + ((unsigned)tid >> 4);
+                if (ci < nc) {
+                    double d;
+                    unsigned di;
+                    eval_chunk_pair(v, g, ctl->cand[ci], tid & 15, d, di);
+                    if (better(d, di, e, idx)) { e = d; idx = di; }
+                }
+            }
+            wave_best(e, idx);
+            if (tid == 0) { ctl->bestE = e; ctl->bestIdx = idx; ctl->ncand = 0; }
+        }
+        __syncthreads();
+        e = ctl->bestE;
+        idx = ctl->bestIdx;
+    }
+}
+
+// reverse tour[i+1..j] (two_opt.py:42) and keep the filter window consistent
+template <typename T, int Q>
+__device__ void apply_move(const View<T>& v, const Geo& g, int tid, unsigned idx)
+{
+    const int i = (int)(idx >> 16), j = (int)(idx & 0xffffu);
+    const int n = g.n;
+    const int L = j - i;
+    const int h = L >> 1;
+    for (int k = tid; k < h; k += g.nt) {
+        const int p = i + 1 + k, p2 = j - k;
+        const uint16_t ta = v.tour[p], tb = v.tour[p2];
+        v.tour[p] = tb;
+        v.tour[p2] = ta;
+        if constexpr (Q != 0) {
+            const float2 a = v.Pq[slot<Q>(p)], b = v.Pq[slot<Q>(p2)];
+            for (int w = p; w < 4 * Q; w += n) v.Pq[slot<Q>(w)] = b;
+            for (int w = p2; w < 4 * Q; w += n) v.Pq[slot<Q>(w)] = a;
+            if (k == 0) {   // p = i+1, p2 = j: the two new boundary edges
+                const float ei = dist32(v.Pq[slot<Q>(i)], b);
+                const float ej = dist32(a, v.Pq[slot<Q>(j + 1)]);
+                for (int w = i; w < 4 * Q; w += n) v.Eq[slot<Q>(w)] = ei;
+                for (int w = j; w < 4 * Q; w += n) v.Eq[slot<Q>(w)] = ej;
+            }
+        }
+    }
+    if constexpr (Q != 0) {
+        const int he = (L - 1) >> 1;            // interior edges i+1..j-1 are mirrored
+        for (int k = tid; k < he; k += g.nt) {
+            const int p = i + 1 + k, p2 = j - 1 - k;
+            const float a = v.Eq[slot<Q>(p)], b = v.Eq[slot<Q>(p2)];
+            for (int w = p; w < 4 * Q; w += n) v.Eq[slot<Q>(w)] = b;
+            for (int w = p2; w < 4 * Q; w += n) v.Eq[slot<Q>(w)] = a;
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// the persistent kernel
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+template <typename T, int Q>
+__global__ void __launch_bounds__(1024) k_two_opt(Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Geo g = p.g;
+    const int n = g.n, tid = threadIdx.x, nt = g.nt;
+    View<T> v;
+    v.ctl = reinterpret_cast<Ctl*>(smem);
+    size_t off = align16(sizeof(Ctl));
+    v.tour = reinterpret_cast<uint16_t*>(smem + off);
+    off += align16(sizeof(uint16_t) * (size_t)(n + 1));
+    v.Pq = reinterpret_cast<float2*>(smem + off);
+    off += sizeof(float2) * 4 * (size_t)Q;
+    v.Eq = reinterpret_cast<float*>(smem + off);
+    off += sizeof(float) * 4 * (size_t)Q;
+    T* xl = reinterpret_cast<T*>(smem + off);
+    Ctl* ctl = v.ctl;
+    if (tid == 0) { ctl->ncand = 0; ctl->ambiguous = 0; }
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) ctl->tour_id = (int)atomicAdd(p.queue, 1u);
+        __syncthreads();
+        const int64_t tk = ctl->tour_id;
+        if (tk >= p.num_tours) break;          // uniform exit: every wave leaves here
+
+        const int64_t grp = tk / p.group_size;
+        int it = 0, target = 0;
+        if (p.mode == kModeForced) {
+            it = p.iters[tk];
+            target = p.target[grp];
+            const int st = p.status ? p.status[tk] : 0;
+            if (it >= target || (st & (TSP2OPT_ST_BAD_INDEX | TSP2OPT_ST_NOT_CLOSED |
+                                       TSP2OPT_ST_NONFINITE | TSP2OPT_ST_RANGE)))
+                continue;
+        }
+        const T* X = reinterpret_cast<const T*>(p.points) + (size_t)(tk / p.tpi) * (size_t)n * 2;
+        int64_t* gt = p.tours + (size_t)tk * (size_t)(n + 1);
+
+        // ---- stage the tour, validate it (no out-of-range index may reach a gather) --------
+        int bad = 0;
+        for (int k = tid; k <= n; k += nt) {
+            const int64_t t = gt[k];
+            if (t < 0 || t >= n) { bad |= TSP2OPT_ST_BAD_INDEX; v.tour[k] = 0; }
+            else v.tour[k] = (uint16_t)t;
+        }
+        if (tid == 0 && gt[0] != gt[n]) bad |= TSP2OPT_ST_NOT_CLOSED;
+        // ---- bounding box of the instance (for centring/scaling the filter copy) -----------
+        double mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
+        for (int k = tid; k < n; k += nt) {
+            const T x = X[2 * k], y = X[2 * k + 1];
+            if (g.xlds) { xl[2 * k] = x; xl[2 * k + 1] = y; }
+            const double dx = (double)x, dy = (double)y;
+            if (!(fabs(dx) <= 1.0e150) || !(fabs(dy) <= 1.0e150))
+                bad |= (dx != dx || dy != dy || fabs(dx) == INFINITY || fabs(dy) == INFINITY)
+                           ? TSP2OPT_ST_NONFINITE : TSP2OPT_ST_RANGE;
+            mnx = fmin(mnx, dx); mxx = fmax(mxx, dx);
+            mny = fmin(mny, dy); mxy = fmax(mxy, dy);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            mnx = fmin(mnx, __shfl_xor(mnx, o)); mxx = fmax(mxx, __shfl_xor(mxx, o));
+            mny = fmin(mny, __shfl_xor(mny, o)); mxy = fmax(mxy, __shfl_xor(mxy, o));
+            bad |= __shfl_xor(bad, o);
+        }
+        if ((tid & 63) == 0) {
+            const int w = tid >> 6;
+            ctl->redd[4 * w] = mnx; ctl->redd[4 * w + 1] = mxx;
+            ctl->redd[4 * w + 2] = mny; ctl->redd[4 * w + 3] = mxy;
+            ctl->pIdx[w] = (unsigned)bad;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < (nt >> 6); ++w) {
+                mnx = fmin(mnx, ctl->redd[4 * w]); mxx = fmax(mxx, ctl->redd[4 * w + 1]);
+                mny = fmin(mny, ctl->redd[4 * w + 2]); mxy = fmax(mxy, ctl->redd[4 * w + 3]);
+                bad |= (int)ctl->pIdx[w];
+            }
+            ctl->flags = bad;
+            ctl->cx = 0.5 * (mnx + mxx);
+            ctl->cy = 0.5 * (mny + mxy);
+            const double half = fmax(0.5 * (mxx - mnx), 0.5 * (mxy - mny));
+            int ex = 0;
+            double sc = 1.0;
+            if (half > 0.0 && half < INFINITY) { (void)frexp(half, &ex); sc = ldexp(1.0, -ex); }
+            ctl->sc = sc;                       // half * sc in [0.5, 1)
+        }
+        __syncthreads();
+        const int flags = ctl->flags;
+        v.X = g.xlds ? xl : X;
+        if (flags != 0) {                       // invalid input: tour untouched (uniform branch)
+            if (tid == 0) {
+                if (p.status) p.status[tk] = flags;
+                if (p.mode == kModeIndep) p.iters[tk] = 0;
+            }
+            continue;
+        }
+        if constexpr (Q != 0) {
+            const double cx = ctl->cx, cy = ctl->cy, sc = ctl->sc;
+            for (int w = tid; w < 4 * Q; w += nt) {
+                const int node = v.tour[w % n];
+                const double x = (double)v.X[2 * node], y = (double)v.X[2 * node + 1];
+                v.Pq[slot<Q>(w)] = make_float2((float)((x - cx) * sc), (float)((y - cy) * sc));
+            }
+            __syncthreads();
+            for (int w = tid; w < 4 * Q; w += nt) {
+                const float e = w + 1 < 4 * Q ? dist32(v.Pq[slot<Q>(w)], v.Pq[slot<Q>(w + 1)]) : 0.f;
+                v.Eq[slot<Q>(w)] = e;
+            }
+        }
+        __syncthreads();
+
+        // ---- improvement loop ----------------------------------------------------------------
+        const long long t_start = p.time_limit_ticks ? wall_clock64() : 0;
+        int sweeps = 0, st = 0;
+        double e;
+        unsigned idx;
+        if (p.mode == kModeIndep) {
+            for (;;) {
+                find_best<T, Q>(v, g, tid, e, idx);
+                ++sweeps;
+                if (!(e < -1.0e-6)) break;                      // two_opt.py:40
+                apply_move<T, Q>(v, g, tid, idx);
+                ++it;
+                if (it >= p.max_iter) { st |= TSP2OPT_ST_CAPPED; break; }   // two_opt.py:47
+                if (p.time_limit_ticks && wall_clock64() - t_start > p.time_limit_ticks) {
+                    st |= TSP2OPT_ST_TIME;                      // plugin two_opt.py:63-65
+                    break;
+                }
+            }
+        } else {
+            // Coupled mode, continuation: the group keeps iterating until `target`; this tour
+            // applies its own strictly negative argmin every iteration (two_opt.py:41-42).
+            // A fixed point (no negative delta) or a proven 2-cycle (same reversal twice in a
+            // row) determines the rest of the trajectory without sweeping.
+            bool have_prev = false, prev_active = false, known = false, active_at_target = false;
+            unsigned prev_idx = kNoMove;
+            while (it < target) {
+                find_best<T, Q>(v, g, tid, e, idx);
+                ++sweeps;
+                const bool active = e < -1.0e-6;
+                if (!(e < 0.0)) { known = true; active_at_target = false; it = target; break; }
+                if (have_prev && idx == prev_idx) {
+                    const int rem = target - it;
+                    if (rem & 1) { apply_move<T, Q>(v, g, tid, idx); active_at_target = prev_active; }
+                    else active_at_target = active;
+                    known = true;
+                    it = target;
+                    break;
+                }
+                apply_move<T, Q>(v, g, tid, idx);
+                have_prev = true; prev_idx = idx; prev_active = active;
+                ++it;
+            }
+            if (!known && target < p.max_iter) {
+                find_best<T, Q>(v, g, tid, e, idx);
+                ++sweeps;
+                active_at_target = e < -1.0e-6;
+            }
+            if (active_at_target && target < p.max_iter && tid == 0) atomicOr(&p.group_flag[grp], 1);
+        }
+
+        // ---- write back ------------------------------------------------------------------------
+        for (int k = tid; k <= n; k += nt) gt[k] = (int64_t)v.tour[k];
+        if (tid == 0) {
+            p.iters[tk] = it;
+            if (p.work_sweeps) p.work_sweeps[tk] += sweeps;
+            if (p.status && p.mode == kModeIndep) p.status[tk] = st;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// coupled mode helpers
+// ------------------------------------------------------------------------------------------
+// target[g] = max over the group's own iteration counts (= the first iteration at which every
+// tour of the group is inactive, unless a tour re-activates: see k_group_lockstep)
+__global__ void k_group_max(const int32_t* iters, int32_t* target, int32_t* group_flag,
+                            int64_t groups, int group_size, unsigned* queue)
+{
+    const int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gidx == 0) *queue = 0;
+    if (gidx >= groups) return;
+    int m = 0;
+    for (int b = 0; b < group_size; ++b) m = max(m, iters[gidx * group_size + b]);
+    target[gidx] = m;
+    group_flag[gidx] = 0;
+}
+
+// General fallback of the coupled mode: one workgroup per flagged group replays the reference's
+// lock-step loop (search/two_opt.py:21-48) from the group's current iteration, with tours and
+// coordinates in global memory.  Only reached if a tour is active again at the group's target,
+// which needs a delta within rounding noise of -1e-6; kept for exactness, not speed.
+template <typename T>
+__global__ void __launch_bounds__(1024) k_group_lockstep(Params p, int32_t* target, int force_all)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = p.g.n, tid = threadIdx.x, nt = blockDim.x;
+    const int64_t grp = blockIdx.x;
+    if (!force_all && p.group_flag[grp] == 0) return;
+    for (int b = 0; b < p.group_size; ++b) {
+        const int st = p.status ? p.status[grp * p.group_size + b] : 0;
+        if (st & (TSP2OPT_ST_BAD_INDEX | TSP2OPT_ST_NOT_CLOSED | TSP2OPT_ST_NONFINITE | TSP2OPT_ST_RANGE))
+            return;                                   // invalid group: left as is
+    }
+    View<T> v;
+    v.ctl = reinterpret_cast<Ctl*>(smem);
+    v.tour = reinterpret_cast<uint16_t*>(smem + align16(sizeof(Ctl)));
+    unsigned* moves = reinterpret_cast<unsigned*>(smem + align16(sizeof(Ctl)) +
+                                                  align16(sizeof(uint16_t) * (size_t)(n + 1)));
+    v.Pq = nullptr; v.Eq = nullptr;
+    v.X = reinterpret_cast<const T*>(p.points) +
+          (size_t)((grp * p.group_size) / p.tpi) * (size_t)n * 2;
+    Geo g = p.g;
+    g.nt = nt;
+    int it = target[grp];
+    while (it < p.max_iter) {
+        bool any = false;
+        for (int b = 0; b < p.group_size; ++b) {
+            int64_t* gt = p.tours + (size_t)(grp * p.group_size + b) * (size_t)(n + 1);
+            __syncthreads();
+            for (int k = tid; k <= n; k += nt) v.tour[k] = (uint16_t)gt[k];
+            __syncthreads();
+            double e;
+            unsigned idx;
+            exact_sweep(v, n, tid, nt, e, idx);
+            block_best(v.ctl, tid, nt, e, idx);
+            if (tid == 0) moves[b] = idx;
+            any = any || (e < -1.0e-6);
+        }
+        if (!any) break;
+        __syncthreads();
+        for (int b = 0; b < p.group_size; ++b) {
+            int64_t* gt = p.tours + (size_t)(grp * p.group_size + b) * (size_t)(n + 1);
+            const unsigned idx = moves[b];
+            const int i = (int)(idx >> 16), j = (int)(idx & 0xffffu), h = (j - i) >> 1;
+            for (int k = tid; k < h; k += nt) {
+                const int64_t a = gt[i + 1 + k], c = gt[j - k];
+                gt[i + 1 + k] = c;
+                gt[j - k] = a;
+            }
+        }
+        __threadfence_block();
+        ++it;
+    }
+    if (tid == 0) target[grp] = it;
+}
+
+__global__ void k_group_finish(int32_t* iters, int32_t* sweeps, int32_t* status,
+                               const int32_t* target, int64_t num_tours, int group_size, int max_iter)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= num_tours) return;
+    const int t = target[k / group_size];
+    if (status && (status[k] & (TSP2OPT_ST_BAD_INDEX | TSP2OPT_ST_NOT_CLOSED |
+                                TSP2OPT_ST_NONFINITE | TSP2OPT_ST_RANGE))) {
+        if (iters) iters[k] = 0;
+        if (sweeps) sweeps[k] = 0;
+        return;
+    }
+    if (iters) iters[k] = t;
+    if (sweeps) sweeps[k] = t >= max_iter ? t : t + 1;
+    if (status) status[k] = t >= max_iter ? TSP2OPT_ST_CAPPED : 0;
+}
+
+__global__ void k_indep_finish(const int32_t* iters, int32_t* sweeps, const int32_t* status,
+                               int64_t num_tours, int max_iter)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= num_tours || !sweeps) return;
+    const int st = status ? status[k] : 0;
+    if (st & (TSP2OPT_ST_BAD_INDEX | TSP2OPT_ST_NOT_CLOSED | TSP2OPT_ST_NONFINITE | TSP2OPT_ST_RANGE))
+        sweeps[k] = 0;
+    else
+        sweeps[k] = (st & (TSP2OPT_ST_CAPPED | TSP2OPT_ST_TIME)) ? iters[k] : iters[k] + 1;
+}
+
+// closed tour length, one wave per tour, summed in double
+template <typename T>
+__global__ void k_lengths(const T* points, const int64_t* tours, double* out, int64_t num_tours,
+                          int n, int tpi)
+{
+    const int64_t tk = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tk >= num_tours) return;
+    const int lane = threadIdx.x & 63;
+    const T* X = points + (size_t)(tk / tpi) * (size_t)n * 2;
+    const int64_t* t = tours + (size_t)tk * (size_t)(n + 1);
+    double s = 0.0;
+    for (int k = lane; k < n; k += 64) {
+        const int64_t a = t[k], b = t[k + 1];
+        if (a < 0 || a >= n || b < 0 || b >= n) { s = NAN; continue; }
+        const double dx = (double)X[2 * a] - (double)X[2 * b];
+        const double dy = (double)X[2 * a + 1] - (double)X[2 * b + 1];
+        s += __builtin_sqrt(dx * dx + dy * dy);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[tk] = s;
+}
+
+template <typename T>
+__global__ void k_sqrt_check(const T* in, T* out, int64_t count)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < count) out[k] = sqrt_rn(in[k]);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(TSP2OPT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+struct Plan {
+    Geo g;
+    size_t lds;
+    int S, W;
+};
+
+constexpr size_t kLdsMax = 160 * 1024;
+const int kQClasses[] = {64, 128, 256, 512, 1024, 2048};
+
+Plan make_plan(int n, int dtype)
+{
+    Plan pl{};
+    Geo& g = pl.g;
+    const size_t tsz = dtype == TSP2OPT_DTYPE_F64 ? 8 : 4;
+    g.n = n;
+    g.eps2 = dtype == TSP2OPT_DTYPE_F64 ? 2.0f * 0x1p-16f : 2.0f * 0x1p-15f;
+    const size_t base = align16(sizeof(Ctl)) + align16(sizeof(uint16_t) * (size_t)(n + 1));
+    const size_t xbytes = (size_t)n * 2 * tsz;
+    // threads per workgroup: about 500 pairs per lane per sweep
+    int nt = n <= 160 ? 64 : n <= 320 ? 128 : n <= 640 ? 256 : n <= 1280 ? 512 : 1024;
+    g.nt = nt;
+    g.qclass = 0;
+    if (n >= 9) {
+        const int dn = n / 2 - 1;                       // cyclic diagonals 2..n/2
+        const int G = (dn + 3) / 4;
+        const int R = (n + 3) / 4;                      // macro-step rows needed
+        int NS = nt / G;
+        if (NS < 1) NS = 1;
+        if (NS > R) NS = R;
+        const int MS = (R + NS - 1) / NS;
+        const int rows = 4 * NS * MS;
+        const int W = rows + 4 * G + 8;
+        const int q = (W + 3) / 4 + 1;
+        for (int qc : kQClasses) {
+            if (qc >= q && base + (size_t)qc * 48 <= kLdsMax) {
+                g.qclass = qc; g.G = G; g.NS = NS; g.MS = MS;
+                pl.S = 4 * MS; pl.W = W;
+                break;
+            }
+        }
+    }
+    pl.lds = base + (size_t)g.qclass * 48;
+    // cache the exact coordinates in LDS when that still leaves >= 4 workgroups per CU (or fits at all
+    // for single-workgroup-per-CU sizes)
+    g.xlds = 0;
+    if (pl.lds + xbytes <= kLdsMax && (pl.lds + xbytes <= 40 * 1024 || nt >= 512)) {
+        g.xlds = 1;
+        pl.lds += align16(xbytes);
+    }
+    return pl;
+}
+
+template <typename T, int Q>
+int launch_main(const Params& p, const Plan& pl, int device, hipStream_t stream, int* blocks_per_cu)
+{
+    auto kern = k_two_opt<T, Q>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, pl.g.nt, pl.lds));
+    if (per_cu < 1) per_cu = 1;
+    if (blocks_per_cu) { *blocks_per_cu = per_cu; return 0; }
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    int64_t grid = (int64_t)cus * per_cu;
+    if (grid > p.num_tours) grid = p.num_tours;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)pl.g.nt), pl.lds, stream, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+int dispatch_main(const Params& p, const Plan& pl, int device, hipStream_t stream, int* bpc = nullptr)
+{
+    switch (pl.g.qclass) {
+    case 0: return launch_main<T, 0>(p, pl, device, stream, bpc);
+    case 64: return launch_main<T, 64>(p, pl, device, stream, bpc);
+    case 128: return launch_main<T, 128>(p, pl, device, stream, bpc);
+    case 256: return launch_main<T, 256>(p, pl, device, stream, bpc);
+    case 512: return launch_main<T, 512>(p, pl, device, stream, bpc);
+    case 1024: return launch_main<T, 1024>(p, pl, device, stream, bpc);
+    case 2048: return launch_main<T, 2048>(p, pl, device, stream, bpc);
+    }
+    return fail(TSP2OPT_E_ARG, "internal: bad filter class");
+}
+
+// workspace layout: [0,256) control words (queue head at 0); then target[groups], flag[groups],
+// iters[num_tours], work[num_tours], status[num_tours] (each 256-byte aligned)
+struct WsLayout {
+    size_t off_target, off_flag, off_iters, off_work, off_status, total;
+};
+
+WsLayout ws_layout(int64_t num_tours, int group_size)
+{
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t groups = (size_t)(num_tours / (group_size > 0 ? group_size : 1)) + 1;
+    WsLayout w{};
+    size_t o = 256;
+    w.off_target = o; o += up(groups * 4);
+    w.off_flag = o; o += up(groups * 4);
+    w.off_iters = o; o += up((size_t)num_tours * 4 + 4);
+    w.off_work = o; o += up((size_t)num_tours * 4 + 4);
+    w.off_status = o; o += up((size_t)num_tours * 4 + 4);
+    w.total = o;
+    return w;
+}
+
+template <typename T>
+int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* sweeps_out,
+            double* lengths_out, int32_t* status_out, int64_t num_tours, int n, int tpi,
+            int group_size, int max_iter, double time_limit_s, int dtype, int device, void* ws,
+            hipStream_t stream)
+{
+    const Plan pl = make_plan(n, dtype);
+    const WsLayout wl = ws_layout(num_tours, group_size);
+    unsigned char* w8 = static_cast<unsigned char*>(ws);
+    Params p{};
+    p.points = points;
+    p.tours = tours;
+    p.iters = iters_out ? iters_out : reinterpret_cast<int32_t*>(w8 + wl.off_iters);
+    p.work_sweeps = reinterpret_cast<int32_t*>(w8 + wl.off_work);
+    p.status = status_out ? status_out : reinterpret_cast<int32_t*>(w8 + wl.off_status);
+    p.target = reinterpret_cast<int32_t*>(w8 + wl.off_target);
+    p.group_flag = reinterpret_cast<int32_t*>(w8 + wl.off_flag);
+    p.queue = reinterpret_cast<unsigned*>(w8);
+    p.num_tours = num_tours;
+    p.tpi = tpi;
+    p.group_size = group_size;
+    p.max_iter = max_iter;
+    p.mode = kModeIndep;
+    p.time_limit_ticks = 0;
+    p.g = pl.g;
+    if (time_limit_s > 0.0 && group_size == 1) {
+        int khz = 0;
+        HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device));
+        if (khz <= 0) khz = 100000;
+        p.time_limit_ticks = (long long)(time_limit_s * 1000.0 * (double)khz);
+        if (p.time_limit_ticks < 1) p.time_limit_ticks = 1;
+    }
+    // zero the control words, the work counters and (coupled mode) nothing else: target/flag are
+    // written by k_group_max before they are read
+    HIP_TRY(hipMemsetAsync(w8, 0, 256, stream));
+    HIP_TRY(hipMemsetAsync(w8 + wl.off_work, 0, (size_t)num_tours * 4 + 4, stream));
+    if (num_tours == 0) return 0;
+    int rc = dispatch_main<T>(p, pl, device, stream);
+    if (rc) return rc;
+    const unsigned tb = 256;
+    const unsigned tgrid = (unsigned)((num_tours + tb - 1) / tb);
+    if (group_size > 1) {
+        const int64_t groups = num_tours / group_size;
+        int32_t* target = reinterpret_cast<int32_t*>(w8 + wl.off_target);
+        hipLaunchKernelGGL(k_group_max, dim3((unsigned)((groups + tb - 1) / tb)), dim3(tb), 0, stream,
+                           p.iters, target, p.group_flag, groups, group_size, p.queue);
+        HIP_TRY(hipGetLastError());
+        Params pf = p;
+        pf.mode = kModeForced;
+        rc = dispatch_main<T>(pf, pl, device, stream);
+        if (rc) return rc;
+        const int lnt = n <= 256 ? 256 : 1024;
+        const size_t llds = align16(sizeof(Ctl)) + align16(sizeof(uint16_t) * (size_t)(n + 1)) +
+                            align16(sizeof(unsigned) * (size_t)group_size);
+        if (llds > kLdsMax) return fail(TSP2OPT_E_UNSUPPORTED, "group_size too large");
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_lockstep<T>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
+        hipLaunchKernelGGL(k_group_lockstep<T>, dim3((unsigned)groups), dim3(lnt), llds, stream, pf,
+                           target, 0);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_group_finish, dim3(tgrid), dim3(tb), 0, stream, iters_out, sweeps_out,
+                           p.status, target, num_tours, group_size, max_iter);
+        HIP_TRY(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_indep_finish, dim3(tgrid), dim3(tb), 0, stream, p.iters, sweeps_out,
+                           p.status, num_tours, max_iter);
+        HIP_TRY(hipGetLastError());
+    }
+    if (lengths_out) {
+        const unsigned lgrid = (unsigned)((num_tours + 3) / 4);
+        hipLaunchKernelGGL(k_lengths<T>, dim3(lgrid), dim3(256), 0, stream,
+                           reinterpret_cast<const T*>(points), tours, lengths_out, num_tours, n, tpi);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+}  // namespace t2o
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+using namespace t2o;
+
+extern "C" int tsp2opt_version(void) { return TSP2OPT_VERSION; }
+
+extern "C" const char* tsp2opt_last_error(void) { return g_err.c_str(); }
+
+extern "C" int64_t tsp2opt_workspace_bytes(int64_t num_tours, int32_t n, int32_t group_size)
+{
+    if (num_tours < 0 || n < 1 || group_size < 1) return fail(TSP2OPT_E_ARG, "bad size");
+    return (int64_t)ws_layout(num_tours, group_size).total;
+}
+
+extern "C" int tsp2opt_solve(const void* points, int64_t* tours, int32_t* iters_out,
+                             int32_t* sweeps_out, double* lengths_out, int32_t* status_out,
+                             int64_t num_tours, int32_t n, int32_t tours_per_instance,
+                             int32_t group_size, int32_t max_iterations, double time_limit_s,
+                             int32_t dtype, int32_t device, void* workspace, int64_t workspace_bytes,
+                             void* hip_stream)
+{
+    if (num_tours < 0 || n < 1) return fail(TSP2OPT_E_ARG, "num_tours < 0 or n < 1");
+    if (num_tours > 0 && (!points || !tours)) return fail(TSP2OPT_E_ARG, "null points/tours");
+    if (n > TSP2OPT_MAX_N) return fail(TSP2OPT_E_UNSUPPORTED, "n > 65535 is not supported");
+    if (tours_per_instance < 1 || group_size < 1) return fail(TSP2OPT_E_ARG, "tours_per_instance/group_size < 1");
+    if (tours_per_instance % group_size != 0 || num_tours % group_size != 0)
+        return fail(TSP2OPT_E_ARG, "group_size must divide tours_per_instance and num_tours");
+    if (dtype != TSP2OPT_DTYPE_F32 && dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
+    if (max_iterations < 0) return fail(TSP2OPT_E_ARG, "max_iterations < 0");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(TSP2OPT_E_HIP, "hipSetDevice failed");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const size_t need = ws_layout(num_tours, group_size).total;
+    void* ws = workspace;
+    bool own = false;
+    if (!ws) {
+        HIP_TRY(hipMalloc(&ws, need));
+        own = true;
+    } else if ((size_t)workspace_bytes < need) {
+        return fail(TSP2OPT_E_WORKSPACE, "workspace too small");
+    }
+    int rc;
+    if (max_iterations == 0) {
+        // two_opt.py:40-48: the first sweep still runs and, if it finds an improvement, is applied
+        // before the cap is tested; a cap of 0 therefore behaves like a cap of 1.
+        max_iterations = 1;
+    }
+    if (dtype == TSP2OPT_DTYPE_F64)
+        rc = solve_t<double>(points, tours, iters_out, sweeps_out, lengths_out, status_out, num_tours,
+                             n, tours_per_instance, group_size, max_iterations, time_limit_s, dtype,
+                             device, ws, stream);
+    else
+        rc = solve_t<float>(points, tours, iters_out, sweeps_out, lengths_out, status_out, num_tours,
+                            n, tours_per_instance, group_size, max_iterations, time_limit_s, dtype,
+                            device, ws, stream);
+    if (own) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(ws);
+    }
+    return rc;
+}
+
+extern "C" int tsp2opt_tour_lengths(const void* points, const int64_t* tours, double* lengths_out,
+                                    int64_t num_tours, int32_t n, int32_t tours_per_instance,
+                                    int32_t dtype, int32_t device, void* hip_stream)
+{
+    if (num_tours < 0 || n < 1 || tours_per_instance < 1) return fail(TSP2OPT_E_ARG, "bad size");
+    if (num_tours == 0) return 0;
+    if (!points || !tours || !lengths_out) return fail(TSP2OPT_E_ARG, "null pointer");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(TSP2OPT_E_HIP, "hipSetDevice failed");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const unsigned grid = (unsigned)((num_tours + 3) / 4);
+    if (dtype == TSP2OPT_DTYPE_F64)
+        hipLaunchKernelGGL(k_lengths<double>, dim3(grid), dim3(256), 0, stream,
+                           static_cast<const double*>(points), tours, lengths_out, num_tours, n,
+                           tours_per_instance);
+    else if (dtype == TSP2OPT_DTYPE_F32)
+        hipLaunchKernelGGL(k_lengths<float>, dim3(grid), dim3(256), 0, stream,
+                           static_cast<const float*>(points), tours, lengths_out, num_tours, n,
+                           tours_per_instance);
+    else
+        return fail(TSP2OPT_E_ARG, "bad dtype");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int tsp2opt_sqrt_check(const void* in, void* out, int64_t count, int32_t dtype,
+                                  int32_t device, void* hip_stream)
+{
+    if (count < 0 || (count > 0 && (!in || !out))) return fail(TSP2OPT_E_ARG, "bad argument");
+    if (count == 0) return 0;
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(TSP2OPT_E_HIP, "hipSetDevice failed");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const unsigned grid = (unsigned)((count + 255) / 256);
+    if (dtype == TSP2OPT_DTYPE_F64)
+        hipLaunchKernelGGL(k_sqrt_check<double>, dim3(grid), dim3(256), 0, stream,
+                           static_cast<const double*>(in), static_cast<double*>(out), count);
+    else if (dtype == TSP2OPT_DTYPE_F32)
+        hipLaunchKernelGGL(k_sqrt_check<float>, dim3(grid), dim3(256), 0, stream,
+                           static_cast<const float*>(in), static_cast<float*>(out), count);
+    else
+        return fail(TSP2OPT_E_ARG, "bad dtype");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int tsp2opt_plan(int32_t n, int32_t dtype, int32_t device, int32_t* out7)
+{
+    if (n < 1 || n > TSP2OPT_MAX_N || !out7) return fail(TSP2OPT_E_ARG, "bad argument");
+    if (dtype != TSP2OPT_DTYPE_F32 && dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
+    const Plan pl = make_plan(n, dtype);
+    out7[0] = pl.g.nt; out7[1] = pl.g.qclass; out7[2] = (int32_t)pl.lds;
+    out7[3] = pl.g.NS; out7[4] = pl.g.G; out7[5] = pl.g.MS; out7[6] = 0;
+    if (device >= 0) {
+        DeviceGuard guard(device);
+        if (!guard.ok) return fail(TSP2OPT_E_HIP, "hipSetDevice failed");
+        Params p{};
+        p.g = pl.g;
+        int bpc = 0;
+        const int rc = dtype == TSP2OPT_DTYPE_F64 ? dispatch_main<double>(p, pl, device, nullptr, &bpc)
+                                                  : dispatch_main<float>(p, pl, device, nullptr, &bpc);
+        if (rc) return rc;
+        out7[6] = bpc;
+    }
+    return 0;
+}

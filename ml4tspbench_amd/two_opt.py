@@ -1,0 +1,194 @@
+"""Host-side mirror of the reference's legacy 2-opt entry points.
+
+Reference interface (read-only): ``search/two_opt.py`` -- ``batched_two_opt_torch`` (:5-51) and
+``tsp_2opt`` (:54-73), registered as ``LOCAL_SEARCH_CLASS[('tsp', '2opt')]``
+(``search/__init__.py:46``).  Same names, argument meaning, return shapes/dtypes and error
+behaviour; the arithmetic runs in ONE persistent HIP kernel per call (``csrc/tsp2opt.hip``)
+instead of ~25 torch kernels + host syncs per iteration.
+
+There is no CPU path: without ``libtsp2opt_hip.so`` or without a HIP device every function here
+raises.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ArrayLike = Union[np.ndarray, torch.Tensor, list, tuple]
+
+
+@dataclass
+class TwoOptResult:
+    """Device-resident result of one batched call."""
+    tours: torch.Tensor        # (T, N+1) int64
+    iterations: torch.Tensor   # (T,) int32  reference `iterator` of the call each tour belongs to
+    sweeps: torch.Tensor       # (T,) int32  full (i,j) sweeps of the reference algorithm
+    lengths: Optional[torch.Tensor]   # (T,) float64 or None
+    status: torch.Tensor       # (T,) int32  TSP2OPT_ST_* bits
+
+
+def _resolve_device(device) -> torch.device:
+    """Map the reference's ``device`` argument onto a HIP device.
+
+    The reference passes ``"cpu"`` (its default, and rl4co's hard-coded choice,
+    models/rl4co/common/reinforce.py:150) or the lightning module's CUDA device
+    (models/modelzoo/gnn/tsp_gnn.py:208).  This implementation always computes on an MI355X:
+    ``"cpu"``/``None`` select the current HIP device.
+    """
+    if not torch.cuda.is_available():
+        raise _lib.Tsp2optError("no HIP device visible: ml4tspbench_amd has no CPU fallback")
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return torch.device("cuda", torch.cuda.current_device())
+    if dev.index is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+def _dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float64:
+        return _lib.DTYPE_F64
+    if dt == torch.float32:
+        return _lib.DTYPE_F32
+    raise TypeError(f"2-opt supports float32/float64 coordinates, got {dt}")
+
+
+_workspaces: dict = {}
+
+
+def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+    """Per-device scratch, grown on demand and reused (stream-ordered use on the current stream)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+        _workspaces[key] = ws
+    return ws
+
+
+def two_opt_device(points: torch.Tensor, tours: torch.Tensor, *, tours_per_instance: int = 1,
+                   group_size: int = 1, max_iterations: int = 5000,
+                   time_limit: Union[float, str, None] = None, want_lengths: bool = True,
+                   inplace: bool = False) -> TwoOptResult:
+    """Run the whole batch on the GPU that owns ``points``; nothing leaves the device.
+
+    points (I, N, 2) float32/float64, tours (T, N+1) integer, both on the same HIP device.
+    Tour ``k`` uses instance ``k // tours_per_instance`` (base.py:61).  ``group_size`` 1 = every
+    tour stops on its own (plugin semantics); ``P`` = consecutive P tours stop together
+    (``batched_two_opt_torch`` with a (P, N+1) batch).  Asynchronous on the current stream.
+    """
+    if points.device.type != "cuda" or tours.device != points.device:
+        raise ValueError("points and tours must live on the same HIP device")
+    if points.dim() == 2:
+        points = points.unsqueeze(0)
+    if tours.dim() == 1:
+        tours = tours.unsqueeze(0)
+    if points.dim() != 3 or points.shape[-1] != 2 or tours.dim() != 2:
+        raise ValueError("expected points (I, N, 2) and tours (T, N+1)")
+    n = points.shape[1]
+    T = tours.shape[0]
+    if tours.shape[1] != n + 1:
+        raise ValueError(f"tours must have N+1 = {n + 1} columns, got {tours.shape[1]}")
+    if T > points.shape[0] * tours_per_instance:
+        raise ValueError("not enough instances for tours_per_instance")
+    dev = points.device
+    code = _dtype_code(points.dtype)
+    points = points.contiguous()
+    if tours.dtype != torch.int64:
+        out = tours.to(torch.int64).contiguous()
+    else:
+        out = tours.contiguous() if inplace else tours.clone(memory_format=torch.contiguous_format)
+    iters = torch.empty(T, dtype=torch.int32, device=dev)
+    sweeps = torch.empty(T, dtype=torch.int32, device=dev)
+    status = torch.zeros(T, dtype=torch.int32, device=dev)
+    lengths = torch.empty(T, dtype=torch.float64, device=dev) if want_lengths else None
+    tl = 0.0 if time_limit in (None, "auto") else float(time_limit)
+    L = _lib.lib()
+    need = L.tsp2opt_workspace_bytes(T, n, group_size)
+    _lib.check(need, "tsp2opt_workspace_bytes")
+    ws = _workspace(dev, int(need))
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rc = L.tsp2opt_solve(points.data_ptr(), out.data_ptr(), iters.data_ptr(), sweeps.data_ptr(),
+                         lengths.data_ptr() if lengths is not None else None, status.data_ptr(),
+                         T, n, int(tours_per_instance), int(group_size), int(max_iterations), tl,
+                         code, dev.index, ws.data_ptr(), ws.numel(), stream)
+    _lib.check(rc, "tsp2opt_solve")
+    return TwoOptResult(out, iters, sweeps, lengths, status)
+
+
+def raise_on_status(status: np.ndarray) -> None:
+    """Turn per-tour input errors into Python exceptions (the reference would index out of range
+    or silently work on a non-closed sequence)."""
+    bad = np.nonzero(status & (_lib.ST_BAD_INDEX | _lib.ST_NOT_CLOSED | _lib.ST_RANGE))[0]
+    if len(bad):
+        k = int(bad[0])
+        st = int(status[k])
+        why = ("has an index outside [0, N)" if st & _lib.ST_BAD_INDEX else
+               "does not end at its first node" if st & _lib.ST_NOT_CLOSED else
+               "uses coordinates beyond 1e150")
+        raise ValueError(f"tour {k} {why}")
+
+
+def _as_tensor(x: ArrayLike, dev: torch.device, dtype=None) -> torch.Tensor:
+    if isinstance(x, torch.Tensor):
+        t = x.detach()
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.to(dev, non_blocking=False)
+
+
+def batched_two_opt_torch(points: ArrayLike, tour: ArrayLike, max_iterations: int = 5000,
+                          device="cpu"):
+    """Drop-in for ``search/two_opt.py:5-51``.
+
+    ``points`` (N, 2) -- dtype preserved (float32 or float64 arithmetic); ``tour`` (N+1,) or
+    (B, N+1) integer.  All B tours share ``points`` and stop together on the minimum over the
+    whole batch (two_opt.py:35,40).  Accepts numpy arrays (like the reference) or torch tensors on
+    any device.  Returns ``(tours ndarray (B, N+1) int64 -- always 2-D, a new array --, iterator)``.
+    """
+    dev = _resolve_device(device)
+    p = _as_tensor(points, dev)
+    if not p.dtype.is_floating_point:
+        raise TypeError("points must be floating point")
+    t = _as_tensor(tour, dev, torch.int64)
+    if t.dim() == 1:
+        t = t.unsqueeze(0)
+    B = t.shape[0]
+    if B == 0:
+        return np.zeros((0, t.shape[1]), dtype=np.int64), 0
+    res = two_opt_device(p, t, tours_per_instance=B, group_size=B,
+                         max_iterations=max_iterations, want_lengths=False)
+    status = res.status.cpu().numpy()
+    raise_on_status(status)
+    return res.tours.cpu().numpy(), int(res.iterations[0].item())
+
+
+def tsp_2opt(np_points: ArrayLike, tours: ArrayLike, adj_mat=None, device="cpu", **kwargs):
+    """Drop-in for ``search/two_opt.py:54-73`` (registry entry ``('tsp', '2opt')``).
+
+    Casts points to float64 and tours to int64 (two_opt.py:67-68), reads
+    ``kwargs['max_iterations_2opt']`` (default 5000, :65), ignores ``adj_mat`` and every other
+    keyword (the lightning modules splat all CLI args in), and returns a new int64 array of the
+    input's rank: ``(P, N+1)`` or ``(N+1,)``.
+    """
+    max_iterations_2opt = kwargs.get("max_iterations_2opt", 5000)
+    dev = _resolve_device(device)
+    if isinstance(tours, torch.Tensor):
+        t = tours.detach()
+    else:
+        t = torch.from_numpy(np.array(tours))          # two_opt.py:64 np.array(tours)
+    ndim = t.dim()
+    p = _as_tensor(np_points, dev, torch.float64)
+    solved, _ = batched_two_opt_torch(p, t, max_iterations=max_iterations_2opt, device=dev)
+    if ndim == 1:
+        solved = solved[0]
+    return solved

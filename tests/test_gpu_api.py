@@ -1,0 +1,73 @@
+"""GPU tests of the drop-in Python boundary (same call shapes as the reference's
+search/two_opt.py and ml4tsp plugin), checked against the golden vectors / oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tsp_2opt_rank_dtype_and_kwargs():
+    from ml4tspbench_amd import tsp_2opt, get_local_search_func
+    g = load_golden(f"{GOLDEN_DIR}/g8_n100_f32values_f64.npz")
+    pts32 = g["points"][0]                       # float32 values, cast to fp64 inside (two_opt.py:67)
+    tour = g["tours_in"][0]
+    out = tsp_2opt(pts32, tour.tolist(), None, device="cpu", max_iterations_2opt=5000,
+                   parallel_sampling=1, some_other_cli_flag="x")
+    assert out.ndim == 1 and out.dtype == np.int64
+    assert np.array_equal(out, g["tours_out"][0])
+    f = get_local_search_func("tsp", "2opt")
+    out2 = f(pts32, tour[None], None, device=torch.device("cuda", 0))
+    assert out2.shape == (1, 101) and np.array_equal(out2[0], g["tours_out"][0])
+    # int32 tours, torch inputs
+    out3 = f(torch.from_numpy(pts32), torch.from_numpy(tour.astype(np.int32)))
+    assert np.array_equal(out3, g["tours_out"][0])
+
+
+def test_batched_two_opt_torch_grouped_semantics():
+    from ml4tspbench_amd import batched_two_opt_torch
+    g = load_golden(f"{GOLDEN_DIR}/g3_n50_group16_f64.npz")
+    tin = g["tours_in"][:16].copy()
+    keep = tin.copy()
+    out, it = batched_two_opt_torch(g["points"][0], tin, max_iterations=5000, device="cuda")
+    assert out.shape == (16, 51) and it == int(g["iterators"][0])
+    assert np.array_equal(out, g["tours_out"][:16])
+    assert np.array_equal(tin, keep)            # input never mutated (two_opt.py:12)
+    g7 = load_golden(f"{GOLDEN_DIR}/g7_n100_group8_f32.npz")   # dtype of points preserved: fp32 math
+    out, it = batched_two_opt_torch(g7["points"][0], g7["tours_in"][:8])
+    assert np.array_equal(out, g7["tours_out"][:8]) and it == int(g7["iterators"][0])
+    out1, it1 = batched_two_opt_torch(g["points"][0], g["tours_in"][3])     # 1-D in, 2-D out
+    assert out1.shape == (1, 51)
+
+
+def test_plugin_batched_equals_per_tour_reference():
+    from ml4tspbench_amd import ML4TSPNARTwoOpt, ML4TSPARTwoOpt, get_local_search_by_name
+    g = load_golden(f"{GOLDEN_DIR}/g3_n50_group16_as_indep_f64.npz")
+    ls = get_local_search_by_name("2opt")()
+    assert isinstance(ls, ML4TSPNARTwoOpt) and ls.max_iterations_2opt == 5000 and ls.time_limit == "auto"
+    out = ls.local_search(g["tours_in"], g["points"], None, per_tours_num=16)
+    assert isinstance(out, np.ndarray) and np.array_equal(out, g["tours_out"])
+    assert ls.nodes_num == 50
+    # torch tensors on the device, keyword call like narsolver.py:105-108
+    dev = torch.device("cuda", 0)
+    out = ls.local_search(tours=torch.from_numpy(g["tours_in"]).to(dev),
+                          points=torch.from_numpy(g["points"]).to(dev), heatmap=None,
+                          per_tours_num=8, per_heatmap_num=2)
+    assert np.array_equal(out, g["tours_out"])
+    one = ML4TSPARTwoOpt()._local_search(g["tours_in"][5], g["points"][0])
+    assert one.shape == (51,) and np.array_equal(one, g["tours_out"][5])
+
+
+def test_plugin_rejects_invalid_result():
+    from ml4tspbench_amd import ML4TSPNARTwoOpt
+    rng = np.random.default_rng(3)
+    pts = rng.random((1, 12, 2))
+    t = np.append(np.append(0, rng.permutation(np.arange(1, 12))), 0)
+    t[4] = t[5]                                   # not a permutation
+    with pytest.raises(ValueError, match="is not valid"):
+        ML4TSPNARTwoOpt().local_search(t, pts)
+    t2 = np.arange(13); t2[-1] = 0; t2[3] = 99
+    with pytest.raises(ValueError):
+        ML4TSPNARTwoOpt().local_search(t2, pts)

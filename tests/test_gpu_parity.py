@@ -1,0 +1,139 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI of
+libtsp2opt_hip.so, against (a) the golden vectors made by the reference itself and (b) the CPU
+oracle on seeded inputs.  Tours, iteration counts and sweep counts are integers: bit-exact.
+Tour lengths are a double-precision sum in a different order: rtol 1e-12.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import ml4tspbench_amd
+    from ml4tspbench_amd import _lib
+    _lib.lib()                       # fails loudly if the HIP extension is missing
+    assert torch.cuda.is_available()
+    return ml4tspbench_amd
+
+
+def _run(amd, pts, tours, tpi, group, max_it, lengths=True):
+    dev = torch.device("cuda", 0)
+    res = amd.two_opt_device(torch.from_numpy(np.ascontiguousarray(pts)).to(dev),
+                             torch.from_numpy(np.ascontiguousarray(tours)).to(dev),
+                             tours_per_instance=tpi, group_size=group, max_iterations=max_it,
+                             want_lengths=lengths)
+    torch.cuda.synchronize()
+    return (res.tours.cpu().numpy(), res.iterations.cpu().numpy(), res.sweeps.cpu().numpy(),
+            res.lengths.cpu().numpy() if lengths else None, res.status.cpu().numpy())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_device_sqrt_is_correctly_rounded(amd, dtype):
+    """SURVEY hard part (b): the device sqrt used by the exact path must agree with the host's
+    IEEE sqrt to 0 ulp (fp64: 4e7 values; fp32: 4e7 values incl. squared-distance-like ranges)."""
+    from ml4tspbench_amd import _lib
+    rng = np.random.default_rng(7)
+    n = 10_000_000
+    chunks = [rng.random(n), rng.random(n) * 2.0, rng.random(n) ** 8, rng.random(n) * 1e6,
+              np.array([0.0, 0.5, 1.0, 2.0, 4.0, 1e-300, 1e300, 2.0 ** -1060, 3.0, 0.1])]
+    x = np.concatenate(chunks).astype(dtype)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.empty_like(xd)
+    code = _lib.DTYPE_F64 if dtype == np.float64 else _lib.DTYPE_F32
+    rc = _lib.lib().tsp2opt_sqrt_check(xd.data_ptr(), yd.data_ptr(), xd.numel(), code, 0,
+                                       torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    y = yd.cpu().numpy()
+    ref = np.sqrt(x)
+    assert np.array_equal(y, ref), f"{(y != ref).sum()} of {len(x)} differ"
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_gpu_matches_reference_golden(amd, path):
+    g = load_golden(path)
+    pts = g["points"].astype(np.float64) if g["entry"] == "tsp_2opt" else g["points"]
+    out, iters, sweeps, lengths, status = _run(amd, pts, g["tours_in"], g["tours_per_instance"],
+                                               g["group_size"], g["max_iterations"])
+    assert (status & 15).max(initial=0) == 0
+    assert np.array_equal(out, g["tours_out"]), g["name"]
+    per_call = iters[::g["group_size"]]
+    assert np.array_equal(per_call, g["iterators"]), g["name"]
+    assert np.array_equal(iters, np.repeat(per_call, g["group_size"]))
+    capped = per_call >= g["max_iterations"]
+    assert np.array_equal(sweeps[::g["group_size"]], np.where(capped, per_call, per_call + 1))
+
+
+def _random_batch(rng, inst, tpi, n, dtype):
+    pts = rng.random((inst, n, 2)).astype(dtype)
+    tours = np.zeros((inst * tpi, n + 1), dtype=np.int64)
+    for k in range(inst * tpi):
+        tours[k, 1:n] = rng.permutation(np.arange(1, n))
+    return pts, tours
+
+
+CASES = [
+    # n, instances, tours/instance, group, dtype, cap
+    (9, 6, 2, 1, np.float64, 5000), (10, 6, 2, 2, np.float64, 5000), (12, 4, 4, 4, np.float32, 5000),
+    (17, 8, 1, 1, np.float64, 5000), (31, 4, 4, 1, np.float32, 5000), (50, 16, 4, 1, np.float64, 5000),
+    (50, 8, 8, 8, np.float64, 5000), (64, 4, 2, 1, np.float64, 3), (100, 24, 1, 1, np.float64, 5000),
+    (100, 4, 8, 8, np.float32, 5000), (127, 3, 2, 2, np.float64, 5000), (161, 4, 2, 1, np.float64, 5000),
+    (200, 4, 4, 4, np.float64, 5000), (321, 2, 2, 1, np.float32, 5000), (500, 2, 8, 1, np.float64, 5000),
+    (500, 2, 8, 8, np.float64, 5000), (500, 2, 4, 4, np.float32, 5000), (641, 2, 1, 1, np.float64, 5000),
+    (1000, 2, 2, 1, np.float64, 5000), (1000, 1, 4, 4, np.float64, 300), (1500, 1, 2, 1, np.float32, 200),
+]
+
+
+@pytest.mark.parametrize("n,inst,tpi,group,dtype,cap", CASES)
+def test_gpu_matches_oracle_random(amd, oracle, n, inst, tpi, group, dtype, cap):
+    rng = np.random.default_rng(1000 + n * 7 + group)
+    pts, tours = _random_batch(rng, inst, tpi, n, dtype)
+    ref_out, ref_it, ref_sw = oracle.solve(pts, tours, tours_per_instance=tpi, group_size=group,
+                                           max_iterations=cap, threads=8)
+    out, iters, sweeps, lengths, status = _run(amd, pts, tours, tpi, group, cap)
+    assert np.array_equal(out, ref_out)
+    assert np.array_equal(iters, ref_it)
+    assert np.array_equal(sweeps, ref_sw)
+    ref_len = oracle.tour_lengths(pts, ref_out, tpi)
+    np.testing.assert_allclose(lengths, ref_len, rtol=1e-12)
+
+
+def test_gpu_inputs_not_mutated_and_status(amd):
+    rng = np.random.default_rng(5)
+    pts, tours = _random_batch(rng, 4, 1, 40, np.float64)
+    dev = torch.device("cuda", 0)
+    t_dev = torch.from_numpy(tours).to(dev)
+    res = amd.two_opt_device(torch.from_numpy(pts).to(dev), t_dev)
+    torch.cuda.synchronize()
+    assert torch.equal(t_dev.cpu(), torch.from_numpy(tours))
+    assert (res.status.cpu().numpy() == 0).all()
+    # bad index / not closed / NaN coordinates are reported per tour, tours left untouched
+    bad = tours.copy()
+    bad[0, 3] = 40
+    bad[1, -1] = 5
+    p2 = pts.copy()
+    p2[2, 7, 0] = np.nan
+    out, iters, sweeps, _, status = _run(amd, p2, bad, 1, 1, 5000)
+    from ml4tspbench_amd import _lib
+    assert status[0] & _lib.ST_BAD_INDEX and status[1] & _lib.ST_NOT_CLOSED and status[2] & _lib.ST_NONFINITE
+    assert status[3] == 0
+    assert np.array_equal(out[:3], bad[:3]) and (iters[:3] == 0).all()
+
+
+def test_gpu_time_limit_stops_early(amd):
+    rng = np.random.default_rng(6)
+    pts, tours = _random_batch(rng, 2, 1, 1000, np.float64)
+    dev = torch.device("cuda", 0)
+    res = amd.two_opt_device(torch.from_numpy(pts).to(dev), torch.from_numpy(tours).to(dev),
+                             time_limit=1e-4)
+    torch.cuda.synchronize()
+    from ml4tspbench_amd import _lib
+    st = res.status.cpu().numpy()
+    assert (st & _lib.ST_TIME).all() and (res.iterations.cpu().numpy() < 600).all()
+    out = res.tours.cpu().numpy()
+    assert (np.sort(out[:, :-1], axis=1) == np.arange(1000)).all()

@@ -1,0 +1,64 @@
+"""The CPU oracle (oracle/two_opt_oracle.c) must reproduce every golden vector bit-for-bit.
+
+The goldens were produced by the reference's own search/two_opt.py (oracle/gen_golden.py);
+this is what pins the oracle.  Integer outputs: exact equality.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_golden
+
+
+def _points_for_entry(g):
+    # tsp_2opt casts to float64 before the loop (search/two_opt.py:67); "batched" keeps the dtype.
+    pts = g["points"]
+    return pts.astype(np.float64) if g["entry"] == "tsp_2opt" else pts
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_oracle_matches_reference_golden(oracle, path):
+    g = load_golden(path)
+    n = g["tours_in"].shape[1] - 1
+    if n >= 5000 and g["max_iterations"] > 8:
+        pytest.skip("covered by test_oracle_large_golden (slow)")
+    out, iters, sweeps = oracle.solve(_points_for_entry(g), g["tours_in"],
+                                      tours_per_instance=g["tours_per_instance"],
+                                      group_size=g["group_size"],
+                                      max_iterations=g["max_iterations"], threads=4)
+    assert np.array_equal(out, g["tours_out"]), g["name"]
+    per_call = iters[::g["group_size"]]
+    assert np.array_equal(per_call, g["iterators"]), g["name"]
+    # sweeps: iterator+1 when converged, == cap when capped
+    capped = per_call >= g["max_iterations"]
+    assert np.array_equal(sweeps[::g["group_size"]], np.where(capped, per_call, per_call + 1))
+
+
+def test_oracle_large_golden(oracle):
+    paths = [p for p in golden_files() if "n10000_cap32" in p]
+    if not paths:
+        pytest.skip("N=10000 golden not generated")
+    g = load_golden(paths[0])
+    out, iters, _ = oracle.solve(_points_for_entry(g), g["tours_in"],
+                                 max_iterations=g["max_iterations"])
+    assert np.array_equal(out, g["tours_out"])
+    assert np.array_equal(iters, g["iterators"])
+
+
+def test_oracle_does_not_mutate_inputs(oracle):
+    rng = np.random.default_rng(0)
+    pts = rng.random((1, 20, 2))
+    t = np.append(np.append(0, rng.permutation(np.arange(1, 20))), 0)[None]
+    t0 = t.copy()
+    out, _, _ = oracle.solve(pts, t)
+    assert np.array_equal(t, t0)
+    assert sorted(out[0][:-1]) == list(range(20)) and out[0][-1] == 0
+
+
+def test_oracle_lengths_never_increase(oracle):
+    rng = np.random.default_rng(1)
+    pts = rng.random((8, 64, 2))
+    tours = np.stack([np.concatenate([[0], rng.permutation(np.arange(1, 64)), [0]]) for _ in range(8)])
+    out, iters, _ = oracle.solve(pts, tours)
+    l0 = oracle.tour_lengths(pts, tours)
+    l1 = oracle.tour_lengths(pts, out)
+    assert np.all(l1 <= l0 + 1e-12) and np.all(iters > 0)
