@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the batched 2-opt hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config tsp500|tsp100|tsp1000|tsp50]
+                    [--mode independent|grouped] [--dtype f64|f32] [--no-cpu]
+
+One "step" = one pass of the hot path over one batch of synthetic input: ALL tours of the batch are
+driven to their 2-opt local optimum by one tsp2opt_solve call (default workload: BASELINE.json
+configs[2], TSP-500 uniform, 128 instances x 16 tours = 2048 tours per GPU, random start tours as in
+ml4tsp/nar/decoder/random.py:27-29, max_iterations 5000, plugin (independent) termination).
+Inputs are resident in HBM before the timed region.  Multi-GPU: one process per GPU (torch
+distributed, RCCL), every rank solves its own batch of the same shape (weak scaling, no data-path
+collective) and the timed region ends with one all_gather of tours + lengths.
+
+metric: pair-deltas/s = sum over tours of sweeps * (N-1)(N-2)/2 / wall time, sweeps = iterator+1
+when converged else the cap.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (N, instances, tours per instance)
+    "tsp50": (50, 1280, 1),
+    "tsp100": (100, 10000, 1),
+    "tsp500": (500, 128, 16),
+    "tsp1000": (1000, 128, 1),
+}
+FLOP_PER_PAIR = 15.0          # 2 x (2 sub + 2 mul + add + sqrt) + 3 add/sub
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
+
+
+def make_batch(name: str, seed: int, dtype):
+    n, inst, tpi = CONFIGS[name]
+    rng = np.random.default_rng(seed)
+    pts = rng.random((inst, n, 2))                    # generate.py:22-23 uniform U[0,1)^2
+    tours = np.zeros((inst * tpi, n + 1), dtype=np.int64)
+    body = np.arange(1, n)
+    for k in range(inst * tpi):
+        tours[k, 1:n] = rng.permutation(body)         # decoder/random.py:27-29: 0, perm, 0
+    return pts.astype(dtype), tours, tpi
+
+
+def cpu_baseline(name: str, pts: np.ndarray, tours: np.ndarray, tpi: int, group: int, cap: int):
+    """The oracle (oracle/two_opt_oracle.c, a port of the reference algorithm) timed on this box's
+    host cores on a bounded sample of the same workload."""
+    from oracle import two_opt_oracle as orc
+    n = pts.shape[1]
+    threads = max(1, min(16, os.cpu_count() or 1, orc.max_threads()))
+    pairs = (n - 1) * (n - 2) // 2
+    # about 10-30 s of CPU work: ~3e8 pair evaluations per core-second
+    per_tour = pairs * (n * 1.15)
+    want = int(max(threads, min(len(tours), (20.0 * 3.0e8 * threads) / per_tour)))
+    want = max(tpi, (want // tpi) * tpi)
+    want = min(want, len(tours))
+    sub_t = tours[:want]
+    sub_p = pts[: (want + tpi - 1) // tpi]
+    t0 = time.perf_counter()
+    out, iters, sweeps = orc.solve(sub_p, sub_t, tours_per_instance=tpi, group_size=group,
+                                   max_iterations=cap, threads=threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": float(sweeps.astype(np.int64).sum()) * pairs / dt,
+        "unit": "pair-deltas/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"first {want} of {len(tours)} tours of the same batch, {dt:.1f} s, "
+                  f"{want / dt:.2f} tours/s, OpenMP over tours",
+        "tours_per_s": want / dt,
+    }, out, iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="tsp500", choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default="independent", choices=["independent", "grouped"])
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--max-iterations", type=int, default=5000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import ml4tspbench_amd as amd
+    from ml4tspbench_amd import _lib
+    L = _lib.lib()
+    L.tsp2opt_profile_enable(1)
+
+    np_dtype = np.float64 if args.dtype == "f64" else np.float32
+    n, inst, tpi = CONFIGS[args.config]
+    pts, tours, tpi = make_batch(args.config, 1234 + rank, np_dtype)   # seed 1234 (utils/args.py:27)
+    group = tpi if args.mode == "grouped" and tpi > 1 else 1
+    T = len(tours)
+    pairs = (n - 1) * (n - 2) // 2
+    d_pts = torch.from_numpy(pts).to(dev)
+    d_tours = torch.from_numpy(tours).to(dev)
+    gather_t = gather_l = None
+    if world > 1:
+        gather_t = torch.empty((world * T, n + 1), dtype=torch.int64, device=dev)
+        gather_l = torch.empty(world * T, dtype=torch.float64, device=dev)
+
+    def step():
+        res = amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi, group_size=group,
+                                 max_iterations=args.max_iterations, want_lengths=True)
+        if world > 1:       # the only exchange of the path: final gather of tours and lengths
+            dist.all_gather_into_tensor(gather_t, res.tours)
+            dist.all_gather_into_tensor(gather_l, res.lengths)
+        return res
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    fence()
+    kern_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        if args.steps <= 64:        # the event query waits for the kernel; cheap, but keep it bounded
+            m, f = ctypes.c_double(), ctypes.c_double()
+            L.tsp2opt_profile_last_ms(local_rank, ctypes.byref(m), ctypes.byref(f))
+            kern_ms.append((m.value, f.value))
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = float(tdt.item())
+
+    sweeps = res.sweeps.to(torch.int64)
+    iters = res.iterations
+    my_pd = torch.tensor([float(sweeps.sum().item()) * pairs, float(T), float(iters.sum().item()),
+                          float(iters.max().item())], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = my_pd[3:].clone()
+        dist.all_reduce(my_pd, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        my_pd[3] = mx[0]
+    pd_per_step, tours_total, it_sum, it_max = [float(x) for x in my_pd.tolist()]
+    value = pd_per_step * args.steps / dt
+    status = res.status.cpu().numpy()
+    assert (status & 15).max(initial=0) == 0, "input rejected"
+
+    out = None
+    if rank == 0:
+        main_ms = float(np.mean([k[0] for k in kern_ms])) if kern_ms else None
+        forced_ms = float(np.mean([k[1] for k in kern_ms])) if kern_ms else None
+        my_pairs = float(sweeps.sum().item()) * pairs
+        roof = None
+        if main_ms:
+            kernel_ms = main_ms + (forced_ms or 0.0)
+            ach = my_pairs * FLOP_PER_PAIR / (kernel_ms * 1e-3) / 1e12
+            roof = {"bound": "valu", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                    "kernel": "k_two_opt", "kernel_ms": kernel_ms,
+                    "note": "algorithmic 15 FLOP per pair-delta / HIP-event duration of the persistent "
+                            "kernel (rank 0); VALU-bound, HBM traffic is O(N) per tour"}
+        out = {
+            "metric": "2-opt pair-deltas/sec", "value": value, "unit": "pair-deltas/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"TSP-{n} uniform, {inst} instances x {tpi} random start tours "
+                                   f"per GPU, 2-opt to local optimum, max_iterations "
+                                   f"{args.max_iterations}, {args.mode} termination",
+                       "tours_per_gpu": T, "nodes": n, "mode": args.mode,
+                       "parallelism": f"tours sharded over {world} GPU(s), final all_gather only"},
+            "tours_per_s": tours_total * args.steps / dt,
+            "mean_iterations": it_sum / tours_total, "max_iterations_seen": it_max,
+            "roofline": roof,
+        }
+        if not args.no_cpu:
+            cb, ref_out, ref_it = cpu_baseline(args.config, pts, tours, tpi, group, args.max_iterations)
+            k = len(ref_out)
+            same = bool(np.array_equal(res.tours[:k].cpu().numpy(), ref_out)
+                        and np.array_equal(res.iterations[:k].cpu().numpy(), ref_it))
+            cb["gpu_matches_oracle_on_sample"] = same
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = value / cb["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

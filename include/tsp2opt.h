@@ -112,6 +112,16 @@ int tsp2opt_sqrt_check(const void* in, void* out, int64_t count, int32_t dtype, 
  * out[3]=row segments, out[4]=diagonal groups, out[5]=macro steps, out[6]=resident workgroups/CU */
 int tsp2opt_plan(int32_t n, int32_t dtype, int32_t device, int32_t* out7);
 
+/*
+ * Optional timing of the persistent kernel: after tsp2opt_profile_enable(1) every tsp2opt_solve
+ * brackets its main kernel (and, in coupled mode, the continuation kernel) with HIP events on the
+ * caller's stream; tsp2opt_profile_last_ms waits for them and returns the durations of the latest
+ * call on `device` (forced_ms may be NULL).  Measurement aid for bench.py's roofline line; no
+ * counterpart in the reference (it only accumulates time.time() deltas, tsp_gnn.py:168,178).
+ */
+int tsp2opt_profile_enable(int32_t on);
+int tsp2opt_profile_last_ms(int32_t device, double* main_ms, double* forced_ms);
+
 const char* tsp2opt_last_error(void);
 int tsp2opt_version(void);
 

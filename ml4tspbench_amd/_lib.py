@@ -33,6 +33,8 @@ SYMBOLS = (
     "tsp2opt_tour_lengths",
     "tsp2opt_sqrt_check",
     "tsp2opt_plan",
+    "tsp2opt_profile_enable",
+    "tsp2opt_profile_last_ms",
     "tsp2opt_last_error",
     "tsp2opt_version",
 )
@@ -64,6 +66,10 @@ def lib() -> ctypes.CDLL:
     L.tsp2opt_sqrt_check.restype = ctypes.c_int
     L.tsp2opt_plan.argtypes = [i32, i32, i32, ctypes.POINTER(i32)]
     L.tsp2opt_plan.restype = ctypes.c_int
+    L.tsp2opt_profile_enable.argtypes = [i32]
+    L.tsp2opt_profile_enable.restype = ctypes.c_int
+    L.tsp2opt_profile_last_ms.argtypes = [i32, ctypes.POINTER(f64), ctypes.POINTER(f64)]
+    L.tsp2opt_profile_last_ms.restype = ctypes.c_int
     L.tsp2opt_last_error.argtypes = []
     L.tsp2opt_last_error.restype = ctypes.c_char_p
     L.tsp2opt_version.argtypes = []

@@ -777,6 +777,25 @@ struct DeviceGuard {
     }
 };
 
+// optional timing of the persistent kernel with HIP events on the caller's stream
+// (tsp2opt_profile_enable / tsp2opt_profile_last_ms; used by bench.py for the roofline figure)
+constexpr int kMaxDev = 16;
+struct ProfSlot {
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // main begin/end, forced begin/end
+    bool have_main = false, have_forced = false;
+};
+int g_profile = 0;
+ProfSlot g_prof[kMaxDev];
+
+int prof_record(int device, int which, hipStream_t stream)
+{
+    if (!g_profile || device < 0 || device >= kMaxDev) return 0;
+    ProfSlot& s = g_prof[device];
+    if (!s.ev[which]) HIP_TRY(hipEventCreate(&s.ev[which]));
+    HIP_TRY(hipEventRecord(s.ev[which], stream));
+    return 0;
+}
+
 struct Plan {
     Geo g;
     size_t lds;
@@ -922,8 +941,13 @@ int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* swe
     HIP_TRY(hipMemsetAsync(w8, 0, 256, stream));
     HIP_TRY(hipMemsetAsync(w8 + wl.off_work, 0, (size_t)num_tours * 4 + 4, stream));
     if (num_tours == 0) return 0;
-    int rc = dispatch_main<T>(p, pl, device, stream);
+    int rc = prof_record(device, 0, stream);
     if (rc) return rc;
+    rc = dispatch_main<T>(p, pl, device, stream);
+    if (rc) return rc;
+    rc = prof_record(device, 1, stream);
+    if (rc) return rc;
+    if (g_profile && device < kMaxDev) { g_prof[device].have_main = true; g_prof[device].have_forced = false; }
     const unsigned tb = 256;
     const unsigned tgrid = (unsigned)((num_tours + tb - 1) / tb);
     if (group_size > 1) {
@@ -934,8 +958,13 @@ int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* swe
         HIP_TRY(hipGetLastError());
         Params pf = p;
         pf.mode = kModeForced;
+        rc = prof_record(device, 2, stream);
+        if (rc) return rc;
         rc = dispatch_main<T>(pf, pl, device, stream);
         if (rc) return rc;
+        rc = prof_record(device, 3, stream);
+        if (rc) return rc;
+        if (g_profile && device < kMaxDev) g_prof[device].have_forced = true;
         const int lnt = n <= 256 ? 256 : 1024;
         const size_t llds = align16(sizeof(Ctl)) + align16(sizeof(uint16_t) * (size_t)(n + 1)) +
                             align16(sizeof(unsigned) * (size_t)group_size);
@@ -1070,6 +1099,34 @@ extern "C" int tsp2opt_sqrt_check(const void* in, void* out, int64_t count, int3
     else
         return fail(TSP2OPT_E_ARG, "bad dtype");
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int tsp2opt_profile_enable(int32_t on)
+{
+    g_profile = on ? 1 : 0;
+    return 0;
+}
+
+extern "C" int tsp2opt_profile_last_ms(int32_t device, double* main_ms, double* forced_ms)
+{
+    if (device < 0 || device >= kMaxDev || !main_ms) return fail(TSP2OPT_E_ARG, "bad argument");
+    ProfSlot& s = g_prof[device];
+    if (!s.have_main) return fail(TSP2OPT_E_ARG, "no profiled call on this device");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(TSP2OPT_E_HIP, "hipSetDevice failed");
+    float ms = 0.f;
+    HIP_TRY(hipEventSynchronize(s.ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms, s.ev[0], s.ev[1]));
+    *main_ms = ms;
+    if (forced_ms) {
+        *forced_ms = 0.0;
+        if (s.have_forced) {
+            HIP_TRY(hipEventSynchronize(s.ev[3]));
+            HIP_TRY(hipEventElapsedTime(&ms, s.ev[2], s.ev[3]));
+            *forced_ms = ms;
+        }
+    }
     return 0;
 }
 
