@@ -122,6 +122,17 @@ int tsp2opt_plan(int32_t n, int32_t dtype, int32_t device, int32_t* out7);
 int tsp2opt_profile_enable(int32_t on);
 int tsp2opt_profile_last_ms(int32_t device, double* main_ms, double* forced_ms);
 
+/*
+ * Diagnostic build aid (no counterpart in the reference): with on != 0 the persistent kernel also
+ * accumulates shader-clock cycles per phase into workspace bytes [64,104) as five uint64:
+ * filter sweep, argmin selection (reductions + exact re-evaluation), reversal, staging, whole tour
+ * (thread 0 of each workgroup, summed over tours).  Never quote run times of such a launch.
+ */
+int tsp2opt_debug_phase_cycles(int32_t on);
+/* Diagnostic: sweeps > 0 makes tsp2opt_solve run only that many filter sweeps per tour (hot loop in
+ * isolation: no argmin selection, no reversal; tours unchanged).  0 restores normal operation. */
+int tsp2opt_debug_sweep_only(int32_t sweeps);
+
 const char* tsp2opt_last_error(void);
 int tsp2opt_version(void);
 

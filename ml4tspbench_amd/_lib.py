@@ -35,6 +35,8 @@ SYMBOLS = (
     "tsp2opt_plan",
     "tsp2opt_profile_enable",
     "tsp2opt_profile_last_ms",
+    "tsp2opt_debug_phase_cycles",
+    "tsp2opt_debug_sweep_only",
     "tsp2opt_last_error",
     "tsp2opt_version",
 )
@@ -70,6 +72,10 @@ def lib() -> ctypes.CDLL:
     L.tsp2opt_profile_enable.restype = ctypes.c_int
     L.tsp2opt_profile_last_ms.argtypes = [i32, ctypes.POINTER(f64), ctypes.POINTER(f64)]
     L.tsp2opt_profile_last_ms.restype = ctypes.c_int
+    L.tsp2opt_debug_phase_cycles.argtypes = [i32]
+    L.tsp2opt_debug_phase_cycles.restype = ctypes.c_int
+    L.tsp2opt_debug_sweep_only.argtypes = [i32]
+    L.tsp2opt_debug_sweep_only.restype = ctypes.c_int
     L.tsp2opt_last_error.argtypes = []
     L.tsp2opt_last_error.restype = ctypes.c_char_p
     L.tsp2opt_version.argtypes = []

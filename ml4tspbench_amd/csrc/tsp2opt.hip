@@ -13,10 +13,15 @@
 //
 // Hot loop ("filter sweep"): the pair triangle is re-indexed as CYCLIC DIAGONALS (r, (r+d) mod N),
 // d = 2..N/2, which is a rectangle (no triangle waste) and along which D(r+1,c+1) of one pair is
-// D(r,c) of the next, so each pair costs ONE distance.  A lane owns 4 adjacent diagonals and walks
-// rows in macro steps of 4 (16 pairs, 16 sqrt), with tour-ordered, centred and scaled fp32
-// coordinates staged in LDS in a 4-way interleaved layout (conflict-free ds_read_b64, uniform row
-// reads broadcast).  The fp32 value is only a FILTER with a proven error bound eps: every lane keeps
+// D(r,c) of the next, so each pair costs ONE distance.  A lane owns two groups of 4 adjacent
+// diagonals ("streams" A and B, GP groups apart) and walks rows in macro steps of 4 (32 pairs,
+// 32 sqrt).  Every value of the step is an (A, B) register pair, so the subtractions, squares and
+// sums issue as v_pk_add/v_pk_mul/v_pk_fma_f32 (measured on MI355X: 25 SIMD-cycles per 64 pairs
+// against 37 for the scalar form, tools/valu_chain_microbench.hip).  Tour-ordered, centred and
+// scaled fp32 coordinates sit in LDS as three 4-way interleaved arrays (x, y, edge length) whose
+// entries are already the (A, B) pairs: entry i holds the value of window group i and of group
+// i+GP, so one conflict-free ds_read_b64 per operand feeds the packed math with no register moves;
+// row operands are broadcast reads of the same arrays.  The fp32 value is only a FILTER with a proven error bound eps: every lane keeps
 // its best macro-step a1 and runner-up a2; after a workgroup min m, only macro steps with
 // a1 <= m + 2 eps can hold the true argmin and are re-evaluated EXACTLY (reference dtype, reference
 // operation order) by wave 0; if some lane's runner-up is also inside the window the workgroup
@@ -54,7 +59,8 @@ struct Geo {                          // launch geometry of the filter sweep (ho
     int n;                            // nodes
     int nt;                           // threads per workgroup
     int qclass;                       // 0: exact-only kernel; else sub-array stride Q
-    int G;                            // lane groups of 4 diagonals
+    int GP;                           // lane groups; a lane owns diagonal groups gp and gp + GP
+    int G;                            // = 2 * GP groups of 4 diagonals (cyclic diagonals 2..4G+1)
     int NS;                           // row segments
     int MS;                           // macro steps (4 rows) per segment
     int xlds;                         // exact coordinates cached in LDS
@@ -76,7 +82,14 @@ struct Params {
     int max_iter;
     int mode;
     long long time_limit_ticks;       // wall_clock64 ticks, 0 = none
+    unsigned long long* stamps;       // optional phase timers (tsp2opt_debug_phase_cycles), else null
+    int dbg_sweeps;                   // > 0: diagnostic, run only this many filter sweeps per tour
     Geo g;
+};
+
+struct Prof {                         // per-thread phase timers, only live when Params::stamps != null
+    bool on;
+    unsigned long long sweep, select, apply;
 };
 
 struct Ctl {                          // LDS control block (first bytes of dynamic LDS)
@@ -84,6 +97,7 @@ struct Ctl {                          // LDS control block (first bytes of dynam
     double pE[kMaxWaves];
     unsigned pIdx[kMaxWaves];
     float wmin[kMaxWaves];
+    int pAmb[kMaxWaves];
     unsigned cand[kMaxCand];
     unsigned ncand;
     int ambiguous;
@@ -113,10 +127,19 @@ __device__ __forceinline__ T dist_exact(T ax, T ay, T bx, T by)
 }
 
 // fp32 filter distance: FMA and the raw 1-ulp v_sqrt_f32 are fine here, the error is budgeted.
-__device__ __forceinline__ float dist32(float2 a, float2 b)
+__device__ __forceinline__ float dist32(float ax, float ay, float bx, float by)
 {
-    float dx = a.x - b.x, dy = a.y - b.y;
+    float dx = ax - bx, dy = ay - by;
     return __builtin_amdgcn_sqrtf(__builtin_fmaf(dy, dy, dx * dx));
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));   // (stream A, stream B)
+
+__device__ __forceinline__ v2f dist32x2(float ax, float ay, v2f bx, v2f by)
+{
+    const v2f dx = (v2f){ax, ax} - bx, dy = (v2f){ay, ay} - by;
+    const v2f s = __builtin_elementwise_fma(dy, dy, dx * dx);
+    return (v2f){__builtin_amdgcn_sqrtf(s.x), __builtin_amdgcn_sqrtf(s.y)};
 }
 
 __device__ __forceinline__ bool better(double e, unsigned idx, double be, unsigned bidx)
@@ -124,21 +147,54 @@ __device__ __forceinline__ bool better(double e, unsigned idx, double be, unsign
     return e < be || (e == be && idx < bidx);
 }
 
+// ---- wave64 reductions on DPP (no LDS round trips): quad swaps, half-row and row mirrors, then the
+// row broadcasts; the full result lands in lane 63 and is broadcast with v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int x)
+{
+    return __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xf, false);   // masked-off lanes keep x
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void best_step(double& e, unsigned& idx)
+{
+    const int olo = dpp_i<CTRL, ROW_MASK>(__double2loint(e));
+    const int ohi = dpp_i<CTRL, ROW_MASK>(__double2hiint(e));
+    const unsigned oi = (unsigned)dpp_i<CTRL, ROW_MASK>((int)idx);
+    const double oe = __hiloint2double(ohi, olo);
+    if (better(oe, oi, e, idx)) { e = oe; idx = oi; }
+}
+
+// lexicographic min of (e, idx) over the wave; result in every lane
 __device__ __forceinline__ void wave_best(double& e, unsigned& idx)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double oe = __shfl_xor(e, off);
-        unsigned oi = __shfl_xor(idx, off);
-        if (better(oe, oi, e, idx)) { e = oe; idx = oi; }
-    }
+    best_step<0xB1, 0xf>(e, idx);       // quad_perm [1,0,3,2]
+    best_step<0x4E, 0xf>(e, idx);       // quad_perm [2,3,0,1]
+    best_step<0x141, 0xf>(e, idx);      // row_half_mirror
+    best_step<0x140, 0xf>(e, idx);      // row_mirror
+    best_step<0x142, 0xa>(e, idx);      // row_bcast15 into rows 1 and 3
+    best_step<0x143, 0xc>(e, idx);      // row_bcast31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(e), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(e), 63);
+    idx = (unsigned)__builtin_amdgcn_readlane((int)idx, 63);
+    e = __hiloint2double(hi, lo);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float min_step(float v)
+{
+    return fminf(v, __int_as_float(dpp_i<CTRL, ROW_MASK>(__float_as_int(v))));
 }
 
 __device__ __forceinline__ float wave_min(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-    return v;
+    v = min_step<0xB1, 0xf>(v);
+    v = min_step<0x4E, 0xf>(v);
+    v = min_step<0x141, 0xf>(v);
+    v = min_step<0x140, 0xf>(v);
+    v = min_step<0x142, 0xa>(v);
+    v = min_step<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -148,8 +204,11 @@ template <typename T>
 struct View {
     Ctl* ctl;
     uint16_t* tour;        // n+1 positions
-    float2* Pq;            // 4*Q filter coordinates, slot(w) = (w&3)*Q + (w>>2), w = window index
-    float* Eq;             // 4*Q filter edge lengths e[w] = |P[w] P[w+1]|
+    // filter copy, 4*Q entries each; slot(w) = (w&3)*Q + (w>>2), w = window (cyclic position) index;
+    // entry slot(w) = (value at w, value at w + 4*GP): the two streams of a lane in one 8-byte read
+    v2f* Xq;               // x
+    v2f* Yq;               // y
+    v2f* Eq;               // edge lengths e[w] = |P[w] P[w+1]|
     const T* X;            // exact coordinates, node order (LDS copy or global)
 };
 
@@ -223,55 +282,52 @@ __device__ void block_best(Ctl* ctl, int tid, int nt, double& e, unsigned& idx)
 // filter sweep
 // ------------------------------------------------------------------------------------------
 template <int Q>
-__device__ __forceinline__ void load_block(const float2* Pq, const float* Eq, int b,
-                                           float2 (&C)[4], float (&E)[4])
+__device__ __forceinline__ void load_block(const v2f* Xq, const v2f* Yq, const v2f* Eq, int b,
+                                           v2f (&CX)[4], v2f (&CY)[4], v2f (&E)[4])
 {
-    // C[u] = P[4b+2+u], E[u] = e[4b+1+u]
-    C[0] = Pq[2 * Q + b];
-    C[1] = Pq[3 * Q + b];
-    C[2] = Pq[b + 1];
-    C[3] = Pq[Q + b + 1];
-    E[0] = Eq[Q + b];
-    E[1] = Eq[2 * Q + b];
-    E[2] = Eq[3 * Q + b];
-    E[3] = Eq[b + 1];
+    // per stream: C[u] = P[4b+2+u], E[u] = e[4b+1+u]
+    CX[0] = Xq[2 * Q + b]; CX[1] = Xq[3 * Q + b]; CX[2] = Xq[b + 1]; CX[3] = Xq[Q + b + 1];
+    CY[0] = Yq[2 * Q + b]; CY[1] = Yq[3 * Q + b]; CY[2] = Yq[b + 1]; CY[3] = Yq[Q + b + 1];
+    E[0] = Eq[Q + b]; E[1] = Eq[2 * Q + b]; E[2] = Eq[3 * Q + b]; E[3] = Eq[b + 1];
 }
 
-// One macro step: rows r0..r0+3 (r0 = 4*rowIdx) x diagonals of this lane, 16 pairs.
-//   Cold[u] = P[c0+u], Cnew[u] = P[c0+4+u], Eold[u] = e[c0-1+u], Enew[u] = e[c0+3+u],
+// One macro step: rows r0..r0+3 (r0 = 4*rowIdx) x the lane's 2 x 4 diagonals, 32 pairs.
+// Per stream:  Cold[u] = P[c0+u], Cnew[u] = P[c0+4+u], Eold[u] = e[c0-1+u], Enew[u] = e[c0+3+u],
 //   Dc[q] = D(r0, c0+q) on entry and D(r0+4, c0+4+q) on exit, c0 = r0 + 2 + 4*g.
 template <int Q>
-__device__ __forceinline__ float macro_step(const float2* Pq, const float* Eq, int rowIdx,
-                                            int colIdx, const float2 (&Cold)[4],
-                                            float2 (&Cnew)[4], const float (&Eold)[4],
-                                            float (&Enew)[4], float (&Dc)[4])
+__device__ __forceinline__ float macro_step(const v2f* Xq, const v2f* Yq, const v2f* Eq,
+                                            int rowIdx, int colIdx,
+                                            const v2f (&CXo)[4], const v2f (&CYo)[4], v2f (&CXn)[4],
+                                            v2f (&CYn)[4], const v2f (&Eo)[4], v2f (&En)[4],
+                                            v2f (&Dc)[4])
 {
-    load_block<Q>(Pq, Eq, colIdx, Cnew, Enew);
-    float2 R[4];
-    float er[4];
-    R[0] = Pq[Q + rowIdx];          // P[r0+1]
-    R[1] = Pq[2 * Q + rowIdx];      // P[r0+2]
-    R[2] = Pq[3 * Q + rowIdx];      // P[r0+3]
-    R[3] = Pq[rowIdx + 1];          // P[r0+4]
-    er[0] = Eq[rowIdx];             // e[r0]
-    er[1] = Eq[Q + rowIdx];
-    er[2] = Eq[2 * Q + rowIdx];
-    er[3] = Eq[3 * Q + rowIdx];
+    load_block<Q>(Xq, Yq, Eq, colIdx, CXn, CYn, En);
+    float rx[4], ry[4], er[4];
+    rx[0] = Xq[Q + rowIdx].x;     ry[0] = Yq[Q + rowIdx].x;         // P[r0+1]
+    rx[1] = Xq[2 * Q + rowIdx].x; ry[1] = Yq[2 * Q + rowIdx].x;     // P[r0+2]
+    rx[2] = Xq[3 * Q + rowIdx].x; ry[2] = Yq[3 * Q + rowIdx].x;     // P[r0+3]
+    rx[3] = Xq[rowIdx + 1].x;     ry[3] = Yq[rowIdx + 1].x;         // P[r0+4]
+    er[0] = Eq[rowIdx].x;                                           // e[r0]
+    er[1] = Eq[Q + rowIdx].x;
+    er[2] = Eq[2 * Q + rowIdx].x;
+    er[3] = Eq[3 * Q + rowIdx].x;
     float mm = INFINITY;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        float t[4], Dn[4];
+        v2f t[4], Dn[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int vp = a + q + 1;                   // column point c0 + vp
-            const float2 C = vp < 4 ? Cold[vp] : Cnew[vp - 4];
-            Dn[q] = dist32(R[a], C);                    // D(r0+a+1, c0+a+q+1)
+            Dn[q] = dist32x2(rx[a], ry[a], vp < 4 ? CXo[vp] : CXn[vp - 4],
+                             vp < 4 ? CYo[vp] : CYn[vp - 4]);       // D(r0+a+1, c0+a+q+1)
             const int ve = a + q;                       // column edge c0 + ve
-            const float ec = ve < 3 ? Eold[ve + 1] : Enew[ve - 3];
-            t[q] = (Dc[q] + Dn[q]) - ec;
+            t[q] = (Dc[q] + Dn[q]) - (ve < 3 ? Eo[ve + 1] : En[ve - 3]);
         }
-        const float rm = fminf(fminf(t[0], t[1]), fminf(t[2], t[3])) - er[a];
-        mm = fminf(mm, rm);
+        float m = __builtin_fminf(__builtin_fminf(t[0].x, t[0].y), t[1].x);
+        m = __builtin_fminf(__builtin_fminf(m, t[1].y), t[2].x);
+        m = __builtin_fminf(__builtin_fminf(m, t[2].y), t[3].x);
+        m = __builtin_fminf(m, t[3].y) - er[a];
+        mm = __builtin_fminf(mm, m);
 #pragma unroll
         for (int q = 0; q < 4; ++q) Dc[q] = Dn[q];
     }
@@ -286,49 +342,49 @@ __device__ __forceinline__ void track(float mm, unsigned id, float& a1, float& a
 }
 
 template <int Q>
-__device__ __forceinline__ void filter_sweep(const float2* Pq, const float* Eq, const Geo& g,
-                                             int tid, float& a1, float& a2, unsigned& chunk)
+__device__ __forceinline__ void filter_sweep(const v2f* Xq, const v2f* Yq, const v2f* Eq,
+                                             const Geo& g, int tid, float& a1, float& a2,
+                                             unsigned& chunk)
 {
     a1 = INFINITY;
     a2 = INFINITY;
     chunk = 0;
-    const int units = g.G * g.NS;
+    const int units = g.GP * g.NS;
     for (int u = tid; u < units; u += g.nt) {
-        const int gi = u % g.G, s = u / g.G;
+        const int gp = u % g.GP, s = u / g.GP;
         int rowIdx = s * g.MS;
-        int colIdx = rowIdx + gi + 1;
-        float2 C0[4], C1[4];
-        float E0[4], E1[4], Dc[4];
-        load_block<Q>(Pq, Eq, colIdx - 1, C0, E0);
-        const float2 A0 = Pq[rowIdx];                   // P[r0]
+        int colIdx = rowIdx + gp + 1;
+        v2f CX0[4], CY0[4], CX1[4], CY1[4], E0[4], E1[4], Dc[4];
+        load_block<Q>(Xq, Yq, Eq, colIdx - 1, CX0, CY0, E0);
+        const float ax = Xq[rowIdx].x, ay = Yq[rowIdx].x;   // P[r0]
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Dc[q] = dist32(A0, C0[q]);
+        for (int q = 0; q < 4; ++q) Dc[q] = dist32x2(ax, ay, CX0[q], CY0[q]);
         unsigned id = (unsigned)u * (unsigned)g.MS;
         int m = 0;
         for (; m + 1 < g.MS; m += 2) {
-            float mm = macro_step<Q>(Pq, Eq, rowIdx, colIdx, C0, C1, E0, E1, Dc);
+            float mm = macro_step<Q>(Xq, Yq, Eq, rowIdx, colIdx, CX0, CY0, CX1, CY1, E0, E1, Dc);
             track(mm, id, a1, a2, chunk);
-            mm = macro_step<Q>(Pq, Eq, rowIdx + 1, colIdx + 1, C1, C0, E1, E0, Dc);
+            mm = macro_step<Q>(Xq, Yq, Eq, rowIdx + 1, colIdx + 1, CX1, CY1, CX0, CY0, E1, E0, Dc);
             track(mm, id + 1, a1, a2, chunk);
             rowIdx += 2; colIdx += 2; id += 2;
         }
         if (m < g.MS) {
-            const float mm = macro_step<Q>(Pq, Eq, rowIdx, colIdx, C0, C1, E0, E1, Dc);
+            const float mm = macro_step<Q>(Xq, Yq, Eq, rowIdx, colIdx, CX0, CY0, CX1, CY1, E0, E1, Dc);
             track(mm, id, a1, a2, chunk);
         }
     }
 }
 
-// exact value of pair `pr` (0..15) of macro step `id`; returns packed index
+// exact value of pair `pr` (0..31: stream, row, diagonal) of macro step `id`; returns packed index
 template <typename T>
 __device__ __forceinline__ void eval_chunk_pair(const View<T>& v, const Geo& g, unsigned id, int pr,
                                                 double& e, unsigned& idx)
 {
     const int u = (int)(id / (unsigned)g.MS), m = (int)(id % (unsigned)g.MS);
-    const int gi = u % g.G, s = u / g.G;
+    const int gi = u % g.GP + (pr >> 4) * g.GP, s = u / g.GP;
     const int r0 = 4 * (s * g.MS + m);
     const int c0 = r0 + 2 + 4 * gi;
-    const int a = pr >> 2, q = pr & 3;
+    const int a = (pr >> 2) & 3, q = pr & 3;
     const int r = (r0 + a) % g.n, c = (c0 + a + q) % g.n;
     const int i = r < c ? r : c, j = r < c ? c : r;
     e = exact_delta(v, i, j);
@@ -338,9 +394,11 @@ __device__ __forceinline__ void eval_chunk_pair(const View<T>& v, const Geo& g, 
 // One full argmin (the reference's per-tour torch.min / torch.argmin, two_opt.py:35-38).
 // Returns in every thread: e = min(0, min valid delta), idx = packed (i,j) or kNoMove.
 template <typename T, int Q>
-__device__ void find_best(const View<T>& v, const Geo& g, int tid, double& e, unsigned& idx)
+__device__ void find_best(const View<T>& v, const Geo& g, int tid, double& e, unsigned& idx, Prof& pf)
 {
     Ctl* ctl = v.ctl;
+    unsigned long long t0 = 0;
+    if (pf.on) t0 = clock64();
     if constexpr (Q == 0) {
         exact_sweep(v, g.n, tid, g.nt, e, idx);
         block_best(ctl, tid, g.nt, e, idx);
@@ -348,51 +406,86 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, double& e, un
     } else {
         float a1, a2;
         unsigned chunk;
-        filter_sweep<Q>(v.Pq, v.Eq, g, tid, a1, a2, chunk);
+        __builtin_amdgcn_s_setprio(0);
+        filter_sweep<Q>(v.Xq, v.Yq, v.Eq, g, tid, a1, a2, chunk);
+        // everything between two sweeps is a latency chain that idles most of the workgroup: run it
+        // at high issue priority so the other workgroups' sweeps on this SIMD do not stretch it
+        __builtin_amdgcn_s_setprio(3);
+        if (pf.on) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
+        const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
         const float wm = wave_min(a1);
-        const int nw = g.nt >> 6;
-        if ((tid & 63) == 0) ctl->wmin[tid >> 6] = wm;
+        if (lane == 0) ctl->wmin[wv] = wm;
         __syncthreads();
         float m = ctl->wmin[0];
         for (int w = 1; w < nw; ++w) m = fminf(m, ctl->wmin[w]);
         const float thr = m + g.eps2;
-        if (a1 <= thr) {
-            const unsigned sl = atomicAdd(&ctl->ncand, 1u);
-            if (sl < (unsigned)kMaxCand) ctl->cand[sl] = chunk;
-        }
-        if (a2 <= thr) ctl->ambiguous = 1;
-        __syncthreads();
-        const unsigned nc = ctl->ncand;
-        const bool slow = ctl->ambiguous != 0 || nc > (unsigned)kMaxCand;
-        if (slow) {
-            exact_sweep(v, g.n, tid, g.nt, e, idx);
-            block_best(ctl, tid, g.nt, e, idx);     // ends with a barrier when nw > 1
-            if (nw == 1) __syncthreads();
-            if (tid == 0) { ctl->ncand = 0; ctl->ambiguous = 0; }
-            return;
-        }
-        if (tid < 64) {
-            e = 0.0;
-            idx = kNoMove;
-            if (tid == 0) {     // the pair (0, n-1): cyclically adjacent, not on any walked diagonal
-                const double d = exact_delta(v, 0, g.n - 1);
-                if (d < e) { e = d; idx = (unsigned)(g.n - 1); }
-            }
-            for (unsigned base = 0; base < nc; base += 4) {
-                const unsigned ci = base + ((unsigned)tid >> 4);
-                if (ci < nc) {
+        // each wave re-evaluates its own candidate macro steps exactly (lanes 0..31 = the 32 pairs)
+        unsigned long long cmask = __ballot(a1 <= thr);
+        int amb = __ballot(a2 <= thr) != 0ull || __popcll(cmask) > 8;
+        e = 0.0;
+        idx = kNoMove;
+        if (!amb) {
+            while (cmask) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)cmask) - 1);
+                cmask &= cmask - 1;
+                const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)chunk, src);
+                if (lane < 32) {
                     double d;
                     unsigned di;
-                    eval_chunk_pair(v, g, ctl->cand[ci], tid & 15, d, di);
+                    eval_chunk_pair(v, g, id, lane, d, di);
                     if (better(d, di, e, idx)) { e = d; idx = di; }
                 }
             }
+            if (tid == 32) {    // the pair (0, n-1): cyclically adjacent, not on any walked diagonal
+                const double d = exact_delta(v, 0, g.n - 1);
+                if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
+            }
             wave_best(e, idx);
-            if (tid == 0) { ctl->bestE = e; ctl->bestIdx = idx; ctl->ncand = 0; }
         }
+        if (lane == 0) { ctl->pE[wv] = e; ctl->pIdx[wv] = idx; ctl->pAmb[wv] = amb; }
         __syncthreads();
-        e = ctl->bestE;
-        idx = ctl->bestIdx;
+        e = ctl->pE[0];
+        idx = ctl->pIdx[0];
+        amb = ctl->pAmb[0];
+        for (int w = 1; w < nw; ++w) {
+            const double oe = ctl->pE[w];
+            const unsigned oi = ctl->pIdx[w];
+            amb |= ctl->pAmb[w];
+            if (better(oe, oi, e, idx)) { e = oe; idx = oi; }
+        }
+        if (amb) {      // a lane holds two macro steps inside the window: exact sweep this iteration
+            __syncthreads();
+            exact_sweep(v, g.n, tid, g.nt, e, idx);
+            block_best(ctl, tid, g.nt, e, idx);
+        }
+        if (pf.on) pf.select += clock64() - t0;
+    }
+}
+
+// write the filter copy of position p: every window index w = p (mod n) is the A value of entry
+// slot(w) and the B value of entry slot(w - 4*GP)
+template <int Q, typename T>
+__device__ __forceinline__ void put_xy(const View<T>& v, const Geo& g, int p, float x, float y)
+{
+    for (int w = p; w < 4 * Q; w += g.n) {
+        const int s = slot<Q>(w);
+        v.Xq[s].x = x;
+        v.Yq[s].x = y;
+        if (w >= 4 * g.GP) {
+            const int sb = s - g.GP;        // slot(w - 4*GP): same sub-array, GP entries earlier
+            v.Xq[sb].y = x;
+            v.Yq[sb].y = y;
+        }
+    }
+}
+
+template <int Q, typename T>
+__device__ __forceinline__ void put_e(const View<T>& v, const Geo& g, int p, float e)
+{
+    for (int w = p; w < 4 * Q; w += g.n) {
+        const int s = slot<Q>(w);
+        v.Eq[s].x = e;
+        if (w >= 4 * g.GP) v.Eq[s - g.GP].y = e;
     }
 }
 
@@ -410,14 +503,13 @@ __device__ void apply_move(const View<T>& v, const Geo& g, int tid, unsigned idx
         v.tour[p] = tb;
         v.tour[p2] = ta;
         if constexpr (Q != 0) {
-            const float2 a = v.Pq[slot<Q>(p)], b = v.Pq[slot<Q>(p2)];
-            for (int w = p; w < 4 * Q; w += n) v.Pq[slot<Q>(w)] = b;
-            for (int w = p2; w < 4 * Q; w += n) v.Pq[slot<Q>(w)] = a;
+            const int sp = slot<Q>(p), sp2 = slot<Q>(p2);
+            const float ax = v.Xq[sp].x, ay = v.Yq[sp].x, bx = v.Xq[sp2].x, by = v.Yq[sp2].x;
+            put_xy<Q>(v, g, p, bx, by);
+            put_xy<Q>(v, g, p2, ax, ay);
             if (k == 0) {   // p = i+1, p2 = j: the two new boundary edges
-                const float ei = dist32(v.Pq[slot<Q>(i)], b);
-                const float ej = dist32(a, v.Pq[slot<Q>(j + 1)]);
-                for (int w = i; w < 4 * Q; w += n) v.Eq[slot<Q>(w)] = ei;
-                for (int w = j; w < 4 * Q; w += n) v.Eq[slot<Q>(w)] = ej;
+                put_e<Q>(v, g, i, dist32(v.Xq[slot<Q>(i)].x, v.Yq[slot<Q>(i)].x, bx, by));
+                put_e<Q>(v, g, j, dist32(ax, ay, v.Xq[slot<Q>(j + 1)].x, v.Yq[slot<Q>(j + 1)].x));
             }
         }
     }
@@ -425,9 +517,9 @@ __device__ void apply_move(const View<T>& v, const Geo& g, int tid, unsigned idx
         const int he = (L - 1) >> 1;            // interior edges i+1..j-1 are mirrored
         for (int k = tid; k < he; k += g.nt) {
             const int p = i + 1 + k, p2 = j - 1 - k;
-            const float a = v.Eq[slot<Q>(p)], b = v.Eq[slot<Q>(p2)];
-            for (int w = p; w < 4 * Q; w += n) v.Eq[slot<Q>(w)] = b;
-            for (int w = p2; w < 4 * Q; w += n) v.Eq[slot<Q>(w)] = a;
+            const float a = v.Eq[slot<Q>(p)].x, b = v.Eq[slot<Q>(p2)].x;
+            put_e<Q>(v, g, p, b);
+            put_e<Q>(v, g, p2, a);
         }
     }
     __syncthreads();
@@ -449,14 +541,14 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
     size_t off = align16(sizeof(Ctl));
     v.tour = reinterpret_cast<uint16_t*>(smem + off);
     off += align16(sizeof(uint16_t) * (size_t)(n + 1));
-    v.Pq = reinterpret_cast<float2*>(smem + off);
-    off += sizeof(float2) * 4 * (size_t)Q;
-    v.Eq = reinterpret_cast<float*>(smem + off);
-    off += sizeof(float) * 4 * (size_t)Q;
+    v.Xq = reinterpret_cast<v2f*>(smem + off);
+    off += sizeof(v2f) * 4 * (size_t)Q;
+    v.Yq = reinterpret_cast<v2f*>(smem + off);
+    off += sizeof(v2f) * 4 * (size_t)Q;
+    v.Eq = reinterpret_cast<v2f*>(smem + off);
+    off += sizeof(v2f) * 4 * (size_t)Q;
     T* xl = reinterpret_cast<T*>(smem + off);
     Ctl* ctl = v.ctl;
-    if (tid == 0) { ctl->ncand = 0; ctl->ambiguous = 0; }
-
     for (;;) {
         __syncthreads();
         if (tid == 0) ctl->tour_id = (int)atomicAdd(p.queue, 1u);
@@ -465,6 +557,8 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
         if (tk >= p.num_tours) break;          // uniform exit: every wave leaves here
 
         const int64_t grp = tk / p.group_size;
+        Prof pf{p.stamps != nullptr, 0, 0, 0};
+        const unsigned long long t_tour = pf.on ? clock64() : 0;
         int it = 0, target = 0;
         if (p.mode == kModeForced) {
             it = p.iters[tk];
@@ -538,74 +632,103 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
         if constexpr (Q != 0) {
             const double cx = ctl->cx, cy = ctl->cy, sc = ctl->sc;
             for (int w = tid; w < 4 * Q; w += nt) {
-                const int node = v.tour[w % n];
-                const double x = (double)v.X[2 * node], y = (double)v.X[2 * node + 1];
-                v.Pq[slot<Q>(w)] = make_float2((float)((x - cx) * sc), (float)((y - cy) * sc));
+                const int na = v.tour[w % n], nb = v.tour[(w + 4 * g.GP) % n];
+                const double xa = (double)v.X[2 * na], ya = (double)v.X[2 * na + 1];
+                const double xb = (double)v.X[2 * nb], yb = (double)v.X[2 * nb + 1];
+                v.Xq[slot<Q>(w)] = (v2f){(float)((xa - cx) * sc), (float)((xb - cx) * sc)};
+                v.Yq[slot<Q>(w)] = (v2f){(float)((ya - cy) * sc), (float)((yb - cy) * sc)};
             }
             __syncthreads();
             for (int w = tid; w < 4 * Q; w += nt) {
-                const float e = w + 1 < 4 * Q ? dist32(v.Pq[slot<Q>(w)], v.Pq[slot<Q>(w + 1)]) : 0.f;
-                v.Eq[slot<Q>(w)] = e;
+                const int s0 = slot<Q>(w), s1 = slot<Q>(w + 1 < 4 * Q ? w + 1 : w);
+                const v2f x0 = v.Xq[s0], y0 = v.Yq[s0], x1 = v.Xq[s1], y1 = v.Yq[s1];
+                v.Eq[s0] = (v2f){dist32(x0.x, y0.x, x1.x, y1.x), dist32(x0.y, y0.y, x1.y, y1.y)};
             }
         }
         __syncthreads();
 
         // ---- improvement loop ----------------------------------------------------------------
+        if (pf.on && tid == 0) atomicAdd(&p.stamps[3], clock64() - t_tour);
         const long long t_start = p.time_limit_ticks ? wall_clock64() : 0;
         int sweeps = 0, st = 0;
         double e;
         unsigned idx;
-        if (p.mode == kModeIndep) {
-            for (;;) {
-                find_best<T, Q>(v, g, tid, e, idx);
-                ++sweeps;
-                if (!(e < -1.0e-6)) break;                      // two_opt.py:40
-                apply_move<T, Q>(v, g, tid, idx);
-                ++it;
+        if constexpr (Q != 0) {
+            if (p.dbg_sweeps > 0) {     // diagnostic: pure filter-sweep throughput, no selection/reversal
+                float acc = 0.f;
+                for (int k = 0; k < p.dbg_sweeps; ++k) {
+                    float a1, a2;
+                    unsigned chunk;
+                    filter_sweep<Q>(v.Xq, v.Yq, v.Eq, g, tid, a1, a2, chunk);
+                    acc += a1 + a2 + (float)chunk;
+                    asm volatile("" ::: "memory");
+                }
+                if (acc == 12345.678f) p.iters[tk] = 1;      // keeps the sweeps live
+                if (tid == 0) { p.iters[tk] = p.dbg_sweeps; if (p.status) p.status[tk] = 0; }
+                continue;
+            }
+        }
+        // One loop for both modes (a single inlined copy of the sweep keeps the hot code small).
+        //   independent: stop on the tour's own minimum (two_opt.py:40) or the cap (:47).
+        //   forced (coupled mode, continuation): the group keeps iterating until `target`; this tour
+        //   applies its own strictly negative argmin every iteration (two_opt.py:41-42).  A fixed
+        //   point (no negative delta) or a proven 2-cycle (the same reversal twice in a row) fixes
+        //   the rest of the trajectory without sweeping; otherwise one more sweep at `target` tells
+        //   whether the tour is still active there (then the group is not finished: k_group_lockstep).
+        const bool forced = p.mode == kModeForced;
+        bool have_prev = false, prev_active = false, active_at_target = false;
+        unsigned prev_idx = kNoMove;
+        for (;;) {
+            const bool check_only = forced && it >= target;
+            if (check_only && target >= p.max_iter) break;
+            find_best<T, Q>(v, g, tid, e, idx, pf);
+            ++sweeps;
+            const bool active = e < -1.0e-6;
+            bool stop_after = false;
+            if (!forced) {
+                if (!active) break;                                         // two_opt.py:40
+            } else {
+                if (check_only) { active_at_target = active; break; }
+                if (!(e < 0.0)) { it = target; break; }                     // fixed point: inactive forever
+                if (have_prev && idx == prev_idx) {                         // 2-cycle A -> B -> A
+                    const int rem = target - it;
+                    it = target;
+                    if (!(rem & 1)) { active_at_target = active; break; }
+                    active_at_target = prev_active;
+                    stop_after = true;                                      // one more reversal: back to A
+                }
+                have_prev = true; prev_idx = idx; prev_active = active;
+            }
+            unsigned long long ta = 0;
+            if (pf.on) ta = clock64();
+            apply_move<T, Q>(v, g, tid, idx);
+            if (pf.on) pf.apply += clock64() - ta;
+            if (stop_after) break;
+            ++it;
+            if (!forced) {
                 if (it >= p.max_iter) { st |= TSP2OPT_ST_CAPPED; break; }   // two_opt.py:47
                 if (p.time_limit_ticks && wall_clock64() - t_start > p.time_limit_ticks) {
-                    st |= TSP2OPT_ST_TIME;                      // plugin two_opt.py:63-65
+                    st |= TSP2OPT_ST_TIME;                                  // plugin two_opt.py:63-65
                     break;
                 }
             }
-        } else {
-            // Coupled mode, continuation: the group keeps iterating until `target`; this tour
-            // applies its own strictly negative argmin every iteration (two_opt.py:41-42).
-            // A fixed point (no negative delta) or a proven 2-cycle (same reversal twice in a
-            // row) determines the rest of the trajectory without sweeping.
-            bool have_prev = false, prev_active = false, known = false, active_at_target = false;
-            unsigned prev_idx = kNoMove;
-            while (it < target) {
-                find_best<T, Q>(v, g, tid, e, idx);
-                ++sweeps;
-                const bool active = e < -1.0e-6;
-                if (!(e < 0.0)) { known = true; active_at_target = false; it = target; break; }
-                if (have_prev && idx == prev_idx) {
-                    const int rem = target - it;
-                    if (rem & 1) { apply_move<T, Q>(v, g, tid, idx); active_at_target = prev_active; }
-                    else active_at_target = active;
-                    known = true;
-                    it = target;
-                    break;
-                }
-                apply_move<T, Q>(v, g, tid, idx);
-                have_prev = true; prev_idx = idx; prev_active = active;
-                ++it;
-            }
-            if (!known && target < p.max_iter) {
-                find_best<T, Q>(v, g, tid, e, idx);
-                ++sweeps;
-                active_at_target = e < -1.0e-6;
-            }
-            if (active_at_target && target < p.max_iter && tid == 0) atomicOr(&p.group_flag[grp], 1);
         }
+        if (forced && active_at_target && target < p.max_iter && tid == 0)
+            atomicOr(&p.group_flag[grp], 1);
 
         // ---- write back ------------------------------------------------------------------------
+        __builtin_amdgcn_s_setprio(0);
         for (int k = tid; k <= n; k += nt) gt[k] = (int64_t)v.tour[k];
         if (tid == 0) {
             p.iters[tk] = it;
             if (p.work_sweeps) p.work_sweeps[tk] += sweeps;
             if (p.status && p.mode == kModeIndep) p.status[tk] = st;
+            if (pf.on) {
+                atomicAdd(&p.stamps[0], pf.sweep);
+                atomicAdd(&p.stamps[1], pf.select);
+                atomicAdd(&p.stamps[2], pf.apply);
+                atomicAdd(&p.stamps[4], clock64() - t_tour);
+            }
         }
     }
 }
@@ -648,7 +771,7 @@ __global__ void __launch_bounds__(1024) k_group_lockstep(Params p, int32_t* targ
     v.tour = reinterpret_cast<uint16_t*>(smem + align16(sizeof(Ctl)));
     unsigned* moves = reinterpret_cast<unsigned*>(smem + align16(sizeof(Ctl)) +
                                                   align16(sizeof(uint16_t) * (size_t)(n + 1)));
-    v.Pq = nullptr; v.Eq = nullptr;
+    v.Xq = nullptr; v.Yq = nullptr; v.Eq = nullptr;
     v.X = reinterpret_cast<const T*>(p.points) +
           (size_t)((grp * p.group_size) / p.tpi) * (size_t)n * 2;
     Geo g = p.g;
@@ -785,6 +908,8 @@ struct ProfSlot {
     bool have_main = false, have_forced = false;
 };
 int g_profile = 0;
+int g_dbg_sweeps = 0;                // diagnostic: filter sweeps only (tsp2opt_debug_sweep_only)
+int g_stamps = 0;                    // phase timers into workspace bytes [64, 128)
 ProfSlot g_prof[kMaxDev];
 
 int prof_record(int device, int which, hipStream_t stream)
@@ -818,26 +943,30 @@ Plan make_plan(int n, int dtype)
     int nt = n <= 160 ? 64 : n <= 320 ? 128 : n <= 640 ? 256 : n <= 1280 ? 512 : 1024;
     g.nt = nt;
     g.qclass = 0;
-    if (n >= 9) {
+    {
         const int dn = n / 2 - 1;                       // cyclic diagonals 2..n/2
-        const int G = (dn + 3) / 4;
-        const int R = (n + 3) / 4;                      // macro-step rows needed
-        int NS = nt / G;
-        if (NS < 1) NS = 1;
-        if (NS > R) NS = R;
-        const int MS = (R + NS - 1) / NS;
-        const int rows = 4 * NS * MS;
-        const int W = rows + 4 * G + 8;
-        const int q = (W + 3) / 4 + 1;
-        for (int qc : kQClasses) {
-            if (qc >= q && base + (size_t)qc * 48 <= kLdsMax) {
-                g.qclass = qc; g.G = G; g.NS = NS; g.MS = MS;
-                pl.S = 4 * MS; pl.W = W;
-                break;
+        const int GP = ((dn + 3) / 4 + 1) / 2;          // lane groups, two diagonal groups each
+        const int G = 2 * GP;
+        // every walked diagonal d = 2..4G+1 must be a valid pair distance: d <= n-2
+        if (GP >= 1 && 4 * G + 1 <= n - 2) {
+            const int R = (n + 3) / 4;                  // macro-step rows needed
+            int NS = nt / GP;
+            if (NS < 1) NS = 1;
+            if (NS > R) NS = R;
+            const int MS = (R + NS - 1) / NS;
+            const int rows = 4 * NS * MS;
+            const int W = rows + 4 * G + 8;
+            const int q = (W + 3) / 4 + 1;
+            for (int qc : kQClasses) {
+                if (qc >= q && base + (size_t)qc * 96 <= kLdsMax) {
+                    g.qclass = qc; g.GP = GP; g.G = G; g.NS = NS; g.MS = MS;
+                    pl.S = 4 * MS; pl.W = W;
+                    break;
+                }
             }
         }
     }
-    pl.lds = base + (size_t)g.qclass * 48;
+    pl.lds = base + (size_t)g.qclass * 96;
     // cache the exact coordinates in LDS when that still leaves >= 4 workgroups per CU (or fits at all
     // for single-workgroup-per-CU sizes)
     g.xlds = 0;
@@ -928,6 +1057,8 @@ int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* swe
     p.max_iter = max_iter;
     p.mode = kModeIndep;
     p.time_limit_ticks = 0;
+    p.stamps = g_stamps ? reinterpret_cast<unsigned long long*>(w8 + 64) : nullptr;
+    p.dbg_sweeps = g_dbg_sweeps;
     p.g = pl.g;
     if (time_limit_s > 0.0 && group_size == 1) {
         int khz = 0;
@@ -1127,6 +1258,23 @@ extern "C" int tsp2opt_profile_last_ms(int32_t device, double* main_ms, double* 
             *forced_ms = ms;
         }
     }
+    return 0;
+}
+
+// Diagnostic: with on != 0, wave 0 lane 0 of every workgroup accumulates shader-clock cycles per
+// phase (filter sweep, argmin selection incl. exact re-evaluation, reversal, staging, whole tour)
+// into workspace bytes [64,104); read them back with tsp2opt_debug_read_phase_cycles after a sync.
+extern "C" int tsp2opt_debug_phase_cycles(int32_t on)
+{
+    g_stamps = on ? 1 : 0;
+    return 0;
+}
+
+// Diagnostic: sweeps > 0 makes tsp2opt_solve run only `sweeps` filter sweeps per tour (no argmin
+// selection, no reversal; tours come back unchanged, iters_out = sweeps).  Measures the hot loop alone.
+extern "C" int tsp2opt_debug_sweep_only(int32_t sweeps)
+{
+    g_dbg_sweeps = sweeps > 0 ? sweeps : 0;
     return 0;
 }
 

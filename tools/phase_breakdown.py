@@ -1,0 +1,43 @@
+"""Diagnostic: where does one tour's time go?  Runs a bench config with the kernel's phase stamps
+enabled and prints the share of shader-clock cycles per phase (thread 0 of each workgroup).
+    python tools/phase_breakdown.py [config] [dtype]
+"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+import ml4tspbench_amd as amd
+from ml4tspbench_amd import _lib, two_opt
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "tsp500"
+dt = np.float64 if (len(sys.argv) < 3 or sys.argv[2] == "f64") else np.float32
+pts, tours, tpi = bench.make_batch(cfg, 1234, dt)
+dev = torch.device("cuda", 0)
+d_pts, d_tours = torch.from_numpy(pts).to(dev), torch.from_numpy(tours).to(dev)
+L = _lib.lib()
+amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi)
+torch.cuda.synchronize()
+L.tsp2opt_debug_phase_cycles(1)
+t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+t0.record()
+res = amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi)
+t1.record(); torch.cuda.synchronize()
+ws = list(two_opt._workspaces.values())[0]
+st = ws[64:104].cpu().numpy().view(np.uint64)
+names = ["sweep", "select", "apply", "stage", "tour_total"]
+tot = float(st[4])
+sw = int(res.sweeps.sum().item())
+print(f"{cfg} {dt.__name__}: {t0.elapsed_time(t1):.2f} ms (stamped build), plan={_lib.plan(pts.shape[1], 1 if dt==np.float64 else 0, 0)}")
+for n, v in zip(names, st):
+    print(f"  {n:10s} {int(v):>16d} cycles  {100*float(v)/tot:6.2f} %   per sweep: {float(v)/sw:9.1f}")
+L.tsp2opt_debug_phase_cycles(0)
+# hot loop in isolation
+K = 600
+L.tsp2opt_debug_sweep_only(K)
+amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi); torch.cuda.synchronize()
+t0.record(); amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi); t1.record(); torch.cuda.synchronize()
+L.tsp2opt_debug_sweep_only(0)
+n = pts.shape[1]; pairs = (n - 1) * (n - 2) // 2
+ms = t0.elapsed_time(t1)
+print(f"sweep-only: {K} sweeps x {len(tours)} tours in {ms:.2f} ms -> {K*len(tours)*pairs/ms/1e9:.1f} G useful pair-deltas/s "
+      f"({ms*1e-3*2.4e9*1024/(K*len(tours)*pairs/64):.1f} SIMD-cycles@2.4GHz per 64 pairs)")
