@@ -179,7 +179,7 @@ class ML4TSPARLocalSearch(ML4TSPNARLocalSearch):
     """AR twin of the base class (ar/local_search/base.py:8-85); identical behaviour."""
 
 
-class ML4TSPARTwoOpt(ML4TSPNARTwoOpt):
+class ML4TSPARTwoOpt(ML4TSPNARTwoOpt, ML4TSPARLocalSearch):
     """AR twin (ar/local_search/two_opt.py:9-67): same kernel, same semantics."""
 
 

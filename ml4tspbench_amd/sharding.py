@@ -1,0 +1,77 @@
+"""Multi-GPU sharding of the batched 2-opt: one process per GPU, torch.distributed (RCCL on ROCm).
+
+The path shards by construction: tours are independent (``group_size == 1``) or
+independent groups of ``P`` tours (coupled mode); an instance's tours stay on one rank so each rank
+only touches its own instances' coordinates.  There is NO per-iteration collective: every rank runs
+the persistent kernel on its contiguous block of instances, then ONE ``all_gather`` of tours,
+iteration counts and lengths ends the call (TSP-500 x 2048: 8.2 MB in total).
+
+The reference has no counterpart (its only distributed mechanism is lightning DDP for training,
+models/modelzoo/base/trainer.py:31); this module is the "final gather of tours and lengths" that
+BASELINE.json's north_star asks for.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def partition(num_units: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, balanced [start, stop) blocks of units (instances) per rank; the first
+    ``num_units % world`` ranks get one extra unit."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    base, extra = divmod(num_units, world)
+    out, start = [], 0
+    for r in range(world):
+        stop = start + base + (1 if r < extra else 0)
+        out.append((start, stop))
+        start = stop
+    return out
+
+
+def solve_sharded(points: torch.Tensor, tours: torch.Tensor, *, tours_per_instance: int = 1,
+                  group_size: int = 1, max_iterations: int = 5000,
+                  solver: Optional[Callable] = None, process_group=None):
+    """Solve a batch that every rank holds, each rank doing its block of instances.
+
+    points (I, N, 2), tours (I * tours_per_instance, N+1) -- identical on every rank and on the
+    rank's own device.  ``solver(points, tours, tours_per_instance=, group_size=,
+    max_iterations=)`` must return an object with ``tours``, ``iterations``, ``lengths`` tensors
+    (default: ``two_opt_device``).  Returns ``(tours (T, N+1) int64, iterations (T,) int32,
+    lengths (T,) float64)`` for the WHOLE batch on every rank.
+    """
+    if solver is None:
+        from .two_opt import two_opt_device
+        solver = two_opt_device
+    if tours_per_instance % group_size != 0:
+        raise ValueError("group_size must divide tours_per_instance (a group stays on one rank)")
+    world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+    rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+    inst = points.shape[0]
+    T, n1 = tours.shape
+    if T != inst * tours_per_instance:
+        raise ValueError("tours must hold tours_per_instance rows per instance")
+    blocks = partition(inst, world)
+    i0, i1 = blocks[rank]
+    res = solver(points[i0:i1], tours[i0 * tours_per_instance:i1 * tours_per_instance],
+                 tours_per_instance=tours_per_instance, group_size=group_size,
+                 max_iterations=max_iterations)
+    if world == 1:
+        return res.tours, res.iterations, res.lengths
+    # one padded all_gather per output (blocks differ by at most one instance)
+    cap = max(b - a for a, b in blocks) * tours_per_instance
+    dev = tours.device
+
+    def gather(x: torch.Tensor, fill=0):
+        pad = torch.full((cap,) + tuple(x.shape[1:]), fill, dtype=x.dtype, device=dev)
+        pad[: x.shape[0]] = x
+        out = torch.empty((world * cap,) + tuple(x.shape[1:]), dtype=x.dtype, device=dev)
+        dist.all_gather_into_tensor(out, pad, group=process_group)
+        parts = [out[r * cap: r * cap + (b - a) * tours_per_instance]
+                 for r, (a, b) in enumerate(blocks)]
+        return torch.cat(parts, dim=0)
+
+    return gather(res.tours.to(dev)), gather(res.iterations.to(dev)), gather(res.lengths.to(dev))

@@ -1,0 +1,68 @@
+"""CPU, world_size 2, gloo: the multi-GPU sharding + final gather (ml4tspbench_amd/sharding.py).
+
+The GPU solver cannot run here, so the test injects the CPU oracle as the per-rank solver (the
+oracle is only the stand-in/checker here); what is under test is the host logic: instance blocks,
+group integrity, padding, all_gather order.  The sharded result must equal the unsharded one.
+"""
+import os
+import socket
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_solver(points, tours, *, tours_per_instance, group_size, max_iterations):
+    from oracle import two_opt_oracle as orc
+    out, iters, _ = orc.solve(points.numpy(), tours.numpy(), tours_per_instance=tours_per_instance,
+                              group_size=group_size, max_iterations=max_iterations)
+    lengths = orc.tour_lengths(points.numpy(), out, tours_per_instance)
+    return SimpleNamespace(tours=torch.from_numpy(out), iterations=torch.from_numpy(iters),
+                           lengths=torch.from_numpy(lengths))
+
+
+def _worker(rank, world, port, inst, tpi, group, n, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ml4tspbench_amd.sharding import solve_sharded
+        rng = np.random.default_rng(42)                 # identical batch on every rank
+        pts = rng.random((inst, n, 2))
+        tours = np.zeros((inst * tpi, n + 1), dtype=np.int64)
+        for k in range(inst * tpi):
+            tours[k, 1:n] = rng.permutation(np.arange(1, n))
+        t, it, ln = solve_sharded(torch.from_numpy(pts), torch.from_numpy(tours),
+                                  tours_per_instance=tpi, group_size=group, max_iterations=5000,
+                                  solver=_oracle_solver)
+        ref = _oracle_solver(torch.from_numpy(pts), torch.from_numpy(tours), tours_per_instance=tpi,
+                             group_size=group, max_iterations=5000)
+        ok = (torch.equal(t, ref.tours) and torch.equal(it, ref.iterations)
+              and torch.allclose(ln, ref.lengths, rtol=0, atol=0))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("inst,tpi,group", [(5, 4, 1), (5, 4, 4), (4, 2, 2), (1, 3, 1)])
+def test_sharded_solve_equals_unsharded_world2(inst, tpi, group):
+    from oracle import two_opt_oracle
+    two_opt_oracle.build()
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), inst, tpi, group, 24, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}

@@ -1,0 +1,89 @@
+"""CPU: host-side mirror of the reference interfaces (no GPU, no oracle in the product path)."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_registries_match_reference_names():
+    import ml4tspbench_amd as amd
+    assert amd.get_local_search_func("tsp", "2opt") is amd.tsp_2opt
+    assert amd.LOCAL_SEARCH_CLASS[("tsp", None)] is None
+    assert amd.get_local_search_by_name("2opt") is amd.ML4TSPNARTwoOpt
+    with pytest.raises(ValueError, match="Cannot find the local_search"):
+        amd.get_local_search_by_name("3opt")
+    ls = amd.ML4TSPNARTwoOpt(time_limit=2.0, max_iterations_2opt=7)
+    assert (ls.time_limit, ls.max_iterations_2opt) == (2.0, 7)
+    for attr in ("nodes_num", "device", "tours", "heatmap", "points"):
+        assert getattr(ls, attr) is None
+    assert issubclass(amd.ML4TSPARTwoOpt, amd.ML4TSPARLocalSearch)
+
+
+def test_base_class_loop_mapping_and_validation():
+    """The generic per-tour loop of the base class (base.py:58-72) with a stub _local_search."""
+    from ml4tspbench_amd import ML4TSPNARLocalSearch
+
+    seen = []
+
+    class Stub(ML4TSPNARLocalSearch):
+        def _local_search(self, tour, points, heatmap=None):
+            seen.append((points[0, 0], None if heatmap is None else heatmap[0, 0]))
+            return tour
+
+    n = 5
+    tours = np.tile(np.array([0, 1, 2, 3, 4, 0]), (8, 1))
+    points = np.arange(2 * n * 2, dtype=np.float64).reshape(2, n, 2) * 0 + np.array([10.0, 20.0])[:, None, None]
+    heat = np.arange(4, dtype=np.float64)[:, None, None] * np.ones((4, n, n))
+    out = Stub().local_search(torch.from_numpy(tours), points, heat, per_tours_num=2, per_heatmap_num=2)
+    assert out.shape == (8, 6)
+    # tour idx -> points[idx // 2 // 2], heatmap[idx // 2]   (base.py:61-62)
+    assert [s[0] for s in seen] == [10.0] * 4 + [20.0] * 4
+    assert [s[1] for s in seen] == [0.0, 0.0, 1.0, 1.0, 2.0, 2.0, 3.0, 3.0]
+    bad = tours.copy()
+    bad[3, 2] = 1
+    with pytest.raises(ValueError, match="is not valid"):
+        Stub().local_search(bad, points, None, per_tours_num=4)
+    bad = tours.copy()
+    bad[0] = [1, 2, 3, 4, 0, 1]          # permutation but does not end with 0
+    with pytest.raises(ValueError, match="is not valid"):
+        Stub().local_search(bad, points, None, per_tours_num=4)
+    with pytest.raises(NotImplementedError):
+        ML4TSPNARLocalSearch().local_search(tours, points)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    """No CPU fallback: without a HIP device every front end raises instead of computing."""
+    import ml4tspbench_amd as amd
+    from ml4tspbench_amd._lib import Tsp2optError
+    pts = np.random.default_rng(0).random((12, 2))
+    t = np.append(np.arange(12), 0)
+    with pytest.raises(Tsp2optError, match="no HIP device"):
+        amd.tsp_2opt(pts, t)
+    with pytest.raises(Tsp2optError, match="no HIP device"):
+        amd.batched_two_opt_torch(pts, t)
+    with pytest.raises(Tsp2optError, match="no HIP device"):
+        amd.ML4TSPNARTwoOpt().local_search(t, pts)
+    with pytest.raises(ValueError):
+        amd.two_opt_device(torch.from_numpy(pts), torch.from_numpy(t))   # CPU tensors are rejected
+
+
+def test_product_never_imports_the_oracle():
+    import os, re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ml4tspbench_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+                assert "two_opt_oracle" not in text or f == "_lib.py" and False, f
+
+
+def test_partition_is_contiguous_and_balanced():
+    from ml4tspbench_amd.sharding import partition
+    for units in (0, 1, 7, 8, 9, 128, 1000):
+        for world in (1, 2, 3, 8):
+            blocks = partition(units, world)
+            assert len(blocks) == world and blocks[0][0] == 0 and blocks[-1][1] == units
+            sizes = [b - a for a, b in blocks]
+            assert all(blocks[k][1] == blocks[k + 1][0] for k in range(world - 1))
+            assert max(sizes) - min(sizes) <= 1
