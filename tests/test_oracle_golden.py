@@ -62,3 +62,21 @@ def test_oracle_lengths_never_increase(oracle):
     l0 = oracle.tour_lengths(pts, tours)
     l1 = oracle.tour_lengths(pts, out)
     assert np.all(l1 <= l0 + 1e-12) and np.all(iters > 0)
+
+
+# Fixtures where the reference AS RUN IN THE BUILD CONTAINER (torch CPU + MKL VML sqrt, which is
+# not correctly rounded) differs from the reference with an IEEE sqrt: only inputs where two deltas
+# tie to the last bit -- regular grids, and the fp-noise moves that converged tours of a coupled
+# group keep applying.  See DESIGN.md section 2.
+NATIVE_DIFFERS = {"g9_grid8_group6_f64", "g9_grid8_indep_f64", "g3_n50_group16_f64"}
+
+
+def test_native_run_differs_only_on_tie_heavy_inputs():
+    differing = set()
+    for path in golden_files():
+        g = load_golden(path)
+        if not bool(g["native_equal"]):
+            differing.add(g["name"])
+            # even then both runs are valid 2-opt results of the same tours: same multiset per tour
+            assert np.array_equal(np.sort(g["tours_out"], axis=1), np.sort(g["tours_out_native"], axis=1))
+    assert differing == NATIVE_DIFFERS
