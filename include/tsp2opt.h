@@ -41,6 +41,8 @@ extern "C" {
 #define TSP2OPT_ST_RANGE        8      /* |coordinate| > 1e150: outside the supported range      */
 #define TSP2OPT_ST_CAPPED      16      /* stopped by max_iterations                              */
 #define TSP2OPT_ST_TIME        32      /* stopped by time_limit_s                                */
+#define TSP2OPT_ST_INTERNAL    64      /* multi-workgroup barrier timed out (device oversubscribed
+                                          by another kernel): tour left untouched, retry          */
 
 /* Largest n the kernels accept (tour positions are held as 16-bit values on chip). */
 #define TSP2OPT_MAX_N 65535
@@ -132,6 +134,10 @@ int tsp2opt_debug_phase_cycles(int32_t on);
 /* Diagnostic: sweeps > 0 makes tsp2opt_solve run only that many filter sweeps per tour (hot loop in
  * isolation: no argmin selection, no reversal; tours unchanged).  0 restores normal operation. */
 int tsp2opt_debug_sweep_only(int32_t sweeps);
+/* Test knob for the choice between one workgroup per tour and a cluster of workgroups per tour
+ * (few tours, or n beyond one workgroup's LDS): -1 automatic (default), 0 never cluster, k >= 2 use
+ * up to k workgroups per tour whenever the geometry allows. */
+int tsp2opt_debug_cluster_mode(int32_t mode);
 
 const char* tsp2opt_last_error(void);
 int tsp2opt_version(void);

@@ -21,6 +21,7 @@ ST_NONFINITE = 4
 ST_RANGE = 8
 ST_CAPPED = 16
 ST_TIME = 32
+ST_INTERNAL = 64
 
 MAX_N = 65535
 
@@ -37,6 +38,7 @@ SYMBOLS = (
     "tsp2opt_profile_last_ms",
     "tsp2opt_debug_phase_cycles",
     "tsp2opt_debug_sweep_only",
+    "tsp2opt_debug_cluster_mode",
     "tsp2opt_last_error",
     "tsp2opt_version",
 )
@@ -76,6 +78,8 @@ def lib() -> ctypes.CDLL:
     L.tsp2opt_debug_phase_cycles.restype = ctypes.c_int
     L.tsp2opt_debug_sweep_only.argtypes = [i32]
     L.tsp2opt_debug_sweep_only.restype = ctypes.c_int
+    L.tsp2opt_debug_cluster_mode.argtypes = [i32]
+    L.tsp2opt_debug_cluster_mode.restype = ctypes.c_int
     L.tsp2opt_last_error.argtypes = []
     L.tsp2opt_last_error.restype = ctypes.c_char_p
     L.tsp2opt_version.argtypes = []

@@ -34,6 +34,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -734,6 +735,469 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
 }
 
 // ------------------------------------------------------------------------------------------
+// cluster kernel: several workgroups per tour (few tours, or N beyond one workgroup's LDS)
+// ------------------------------------------------------------------------------------------
+// The (row segment x diagonal group) rectangle of one tour is tiled over CS = CR x CD workgroups.
+// Every workgroup keeps the whole tour (uint16) in LDS and applies every reversal to it, so the
+// tour needs no exchange; its filter copy covers only its own tile: the column pair arrays for
+// window groups [ilo, ilo+Qw) and plain row arrays for its row band.  Per iteration each
+// workgroup finds the exact best move of its tile (same filter + exact re-evaluation as above),
+// publishes (delta, index) in a global slot and meets the others at a counter barrier
+// (agent-scope release/acquire, write-through payload: guide G16); all of them then reduce the CS
+// slots identically and apply the same move.  Entries of the filter copy whose position lies in
+// the reversed segment are re-staged from the tour.  Workgroups of a cluster must be co-resident:
+// the host launches at most one workgroup per CU, and every spin is bounded.
+struct CGeo {
+    int n, nt;
+    int GP;                 // lane groups of the whole tour (stream B = group + GP)
+    int CS, CR, CD;         // workgroups per tour = CR row bands x CD diagonal-group bands
+    int GPw, NSw, MS;       // per workgroup: lane groups, row segments; macro steps per segment
+    int Qw;                 // entries per sub-array of the column pair arrays
+    int rowsw;              // row positions of the band = 4*NSw*MS
+    int xlds;
+    float eps2;
+};
+
+struct CParams {
+    const void* points;
+    int64_t* tours;
+    int32_t* iters;
+    int32_t* work_sweeps;
+    int32_t* status;
+    unsigned* csync;        // per cluster `cstride` dwords: [0] arrivals, [1] abort, [16..] slots
+    int cstride;
+    int64_t num_tours;
+    int tpi;
+    int max_iter;
+    long long time_limit_ticks;
+    int num_clusters;
+    CGeo g;
+};
+
+constexpr unsigned kSpinLimit = 1u << 26;       // bounded wait (about 10 s): never hang the GPU
+constexpr int kSlotDw = 4;                      // delta lo, delta hi, index, flags
+
+template <typename T>
+struct CView {
+    Ctl* ctl;
+    uint16_t* tour;
+    v2f *Xq, *Yq, *Eq;      // column pair arrays, slot = u*Qw + local index
+    float *RX, *RY, *RE;    // row band, natural order
+    const T* X;
+    double cx, cy, sc;
+    int ilo;                // window group of local column index 0
+    int rbase;              // tour position (unwrapped) of local row 0
+    int rs0, gp0;           // first row segment / lane group of this workgroup
+};
+
+template <typename T>
+__device__ __forceinline__ void scaled_pos(const CView<T>& v, int p, float& x, float& y)
+{
+    const int node = v.tour[p];
+    x = (float)(((double)v.X[2 * node] - v.cx) * v.sc);
+    y = (float)(((double)v.X[2 * node + 1] - v.cy) * v.sc);
+}
+
+// (re)build the filter entries whose tour position is in [lo, hi] (coordinates) / [elo, ehi]
+// (edge lengths); positions are taken modulo n
+template <typename T>
+__device__ void stage_c(const CView<T>& v, const CGeo& g, int tid, int lo, int hi, int elo, int ehi)
+{
+    const int n = g.n;
+    for (int k = tid; k < 4 * g.Qw; k += g.nt) {
+        const int il = k >> 2, u = k & 3, sl = u * g.Qw + il;
+        const int w = 4 * (v.ilo + il) + u;
+        const int pa = w % n, pb = (w + 4 * g.GP) % n;
+        if (pa >= lo && pa <= hi) { float x, y; scaled_pos(v, pa, x, y); v.Xq[sl].x = x; v.Yq[sl].x = y; }
+        if (pb >= lo && pb <= hi) { float x, y; scaled_pos(v, pb, x, y); v.Xq[sl].y = x; v.Yq[sl].y = y; }
+        if (pa >= elo && pa <= ehi) {
+            float x0, y0, x1, y1;
+            scaled_pos(v, pa, x0, y0); scaled_pos(v, pa + 1, x1, y1);
+            v.Eq[sl].x = dist32(x0, y0, x1, y1);
+        }
+        if (pb >= elo && pb <= ehi) {
+            float x0, y0, x1, y1;
+            scaled_pos(v, pb, x0, y0); scaled_pos(v, pb + 1, x1, y1);
+            v.Eq[sl].y = dist32(x0, y0, x1, y1);
+        }
+    }
+    for (int k = tid; k < g.rowsw + 8; k += g.nt) {
+        const int pp = (v.rbase + k) % n;
+        if (pp >= lo && pp <= hi) { float x, y; scaled_pos(v, pp, x, y); v.RX[k] = x; v.RY[k] = y; }
+        if (pp >= elo && pp <= ehi) {
+            float x0, y0, x1, y1;
+            scaled_pos(v, pp, x0, y0); scaled_pos(v, pp + 1, x1, y1);
+            v.RE[k] = dist32(x0, y0, x1, y1);
+        }
+    }
+}
+
+__device__ __forceinline__ void load_block_c(const v2f* Xq, const v2f* Yq, const v2f* Eq, int Q, int b,
+                                             v2f (&CX)[4], v2f (&CY)[4], v2f (&E)[4])
+{
+    CX[0] = Xq[2 * Q + b]; CX[1] = Xq[3 * Q + b]; CX[2] = Xq[b + 1]; CX[3] = Xq[Q + b + 1];
+    CY[0] = Yq[2 * Q + b]; CY[1] = Yq[3 * Q + b]; CY[2] = Yq[b + 1]; CY[3] = Yq[Q + b + 1];
+    E[0] = Eq[Q + b]; E[1] = Eq[2 * Q + b]; E[2] = Eq[3 * Q + b]; E[3] = Eq[b + 1];
+}
+
+// same macro step as the single-workgroup kernel, rows from the band arrays (rl = local row of r0)
+__device__ __forceinline__ float macro_step_c(const v2f* Xq, const v2f* Yq, const v2f* Eq, int Q,
+                                              const float* RX, const float* RY, const float* RE,
+                                              int rl, int colIdx, const v2f (&CXo)[4],
+                                              const v2f (&CYo)[4], v2f (&CXn)[4], v2f (&CYn)[4],
+                                              const v2f (&Eo)[4], v2f (&En)[4], v2f (&Dc)[4])
+{
+    load_block_c(Xq, Yq, Eq, Q, colIdx, CXn, CYn, En);
+    float rx[4], ry[4], er[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { rx[a] = RX[rl + 1 + a]; ry[a] = RY[rl + 1 + a]; er[a] = RE[rl + a]; }
+    float mm = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        v2f t[4], Dn[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int vp = a + q + 1;
+            Dn[q] = dist32x2(rx[a], ry[a], vp < 4 ? CXo[vp] : CXn[vp - 4], vp < 4 ? CYo[vp] : CYn[vp - 4]);
+            const int ve = a + q;
+            t[q] = (Dc[q] + Dn[q]) - (ve < 3 ? Eo[ve + 1] : En[ve - 3]);
+        }
+        float m = __builtin_fminf(__builtin_fminf(t[0].x, t[0].y), t[1].x);
+        m = __builtin_fminf(__builtin_fminf(m, t[1].y), t[2].x);
+        m = __builtin_fminf(__builtin_fminf(m, t[2].y), t[3].x);
+        m = __builtin_fminf(m, t[3].y) - er[a];
+        mm = __builtin_fminf(mm, m);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Dc[q] = Dn[q];
+    }
+    return mm;
+}
+
+template <typename T>
+__device__ __forceinline__ void filter_sweep_c(const CView<T>& v, const CGeo& g, int tid, float& a1,
+                                               float& a2, unsigned& chunk)
+{
+    a1 = INFINITY;
+    a2 = INFINITY;
+    chunk = 0;
+    const int units = g.GPw * g.NSw;
+    for (int u = tid; u < units; u += g.nt) {
+        const int gpl = u % g.GPw, sl = u / g.GPw;
+        if (v.gp0 + gpl >= g.GP) continue;              // padding of the last diagonal band
+        int rl = 4 * sl * g.MS;
+        int col = sl * g.MS + gpl + 1;
+        v2f CX0[4], CY0[4], CX1[4], CY1[4], E0[4], E1[4], Dc[4];
+        load_block_c(v.Xq, v.Yq, v.Eq, g.Qw, col - 1, CX0, CY0, E0);
+        const float ax = v.RX[rl], ay = v.RY[rl];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Dc[q] = dist32x2(ax, ay, CX0[q], CY0[q]);
+        unsigned id = (unsigned)u * (unsigned)g.MS;
+        int m = 0;
+        for (; m + 1 < g.MS; m += 2) {
+            float mm = macro_step_c(v.Xq, v.Yq, v.Eq, g.Qw, v.RX, v.RY, v.RE, rl, col, CX0, CY0, CX1, CY1, E0, E1, Dc);
+            track(mm, id, a1, a2, chunk);
+            mm = macro_step_c(v.Xq, v.Yq, v.Eq, g.Qw, v.RX, v.RY, v.RE, rl + 4, col + 1, CX1, CY1, CX0, CY0, E1, E0, Dc);
+            track(mm, id + 1, a1, a2, chunk);
+            rl += 8; col += 2; id += 2;
+        }
+        if (m < g.MS) {
+            const float mm = macro_step_c(v.Xq, v.Yq, v.Eq, g.Qw, v.RX, v.RY, v.RE, rl, col, CX0, CY0, CX1, CY1, E0, E1, Dc);
+            track(mm, id, a1, a2, chunk);
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ double exact_delta_c(const CView<T>& v, int i, int j)
+{
+    View<T> w;
+    w.tour = v.tour;
+    w.X = v.X;
+    return exact_delta(w, i, j);
+}
+
+// exact value of pair `pr` (0..31) of local macro step `id`; false for padding units
+template <typename T>
+__device__ __forceinline__ bool eval_chunk_pair_c(const CView<T>& v, const CGeo& g, unsigned id, int pr,
+                                                  double& e, unsigned& idx)
+{
+    const int u = (int)(id / (unsigned)g.MS), m = (int)(id % (unsigned)g.MS);
+    const int gpl = u % g.GPw, sl = u / g.GPw;
+    const int gp = v.gp0 + gpl;
+    if (gp >= g.GP) return false;
+    const int gi = gp + (pr >> 4) * g.GP;
+    const int r0 = 4 * ((v.rs0 + sl) * g.MS + m);
+    const int c0 = r0 + 2 + 4 * gi;
+    const int a = (pr >> 2) & 3, q = pr & 3;
+    const int r = (r0 + a) % g.n, c = (c0 + a + q) % g.n;
+    const int i = r < c ? r : c, j = r < c ? c : r;
+    e = exact_delta_c(v, i, j);
+    idx = ((unsigned)i << 16) | (unsigned)j;
+    return true;
+}
+
+// best move of this workgroup's tile: e = min(0, min exact delta), idx packed; valid in all threads
+template <typename T>
+__device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool first_wg, double& e,
+                               unsigned& idx)
+{
+    Ctl* ctl = v.ctl;
+    float a1, a2;
+    unsigned chunk;
+    __builtin_amdgcn_s_setprio(0);
+    filter_sweep_c(v, g, tid, a1, a2, chunk);
+    __builtin_amdgcn_s_setprio(3);
+    const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
+    const float wm = wave_min(a1);
+    if (lane == 0) ctl->wmin[wv] = wm;
+    __syncthreads();
+    float m = ctl->wmin[0];
+    for (int w = 1; w < nw; ++w) m = fminf(m, ctl->wmin[w]);
+    const float thr = m + g.eps2;
+    unsigned long long cmask = __ballot(a1 <= thr);
+    int amb = __ballot(a2 <= thr) != 0ull || __popcll(cmask) > 8;
+    e = 0.0;
+    idx = kNoMove;
+    if (!amb) {
+        while (cmask) {
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)cmask) - 1);
+            cmask &= cmask - 1;
+            const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)chunk, src);
+            if (lane < 32) {
+                double d;
+                unsigned di;
+                if (eval_chunk_pair_c(v, g, id, lane, d, di) && better(d, di, e, idx)) { e = d; idx = di; }
+            }
+        }
+        if (first_wg && tid == 32) {        // the pair (0, n-1), once per tour
+            const double d = exact_delta_c(v, 0, g.n - 1);
+            if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
+        }
+        wave_best(e, idx);
+    }
+    if (lane == 0) { ctl->pE[wv] = e; ctl->pIdx[wv] = idx; ctl->pAmb[wv] = amb; }
+    __syncthreads();
+    e = ctl->pE[0];
+    idx = ctl->pIdx[0];
+    amb = ctl->pAmb[0];
+    for (int w = 1; w < nw; ++w) {
+        const double oe = ctl->pE[w];
+        const unsigned oi = ctl->pIdx[w];
+        amb |= ctl->pAmb[w];
+        if (better(oe, oi, e, idx)) { e = oe; idx = oi; }
+    }
+    if (amb) {      // two candidates in one lane: evaluate the whole tile exactly this iteration
+        __syncthreads();
+        e = 0.0;
+        idx = kNoMove;
+        const long long total = (long long)g.GPw * g.NSw * g.MS * 32;
+        for (long long k = tid; k < total; k += g.nt) {
+            double d;
+            unsigned di;
+            if (eval_chunk_pair_c(v, g, (unsigned)(k >> 5), (int)(k & 31), d, di) && better(d, di, e, idx)) {
+                e = d;
+                idx = di;
+            }
+        }
+        if (first_wg && tid == 0) {
+            const double d = exact_delta_c(v, 0, g.n - 1);
+            if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
+        }
+        block_best(ctl, tid, g.nt, e, idx);
+    }
+}
+
+// publish this workgroup's (e, idx), wait for the cluster, reduce all slots.  Returns false on
+// abort (a workgroup of the cluster is missing: spin limit hit).
+__device__ bool cluster_exchange(Ctl* ctl, unsigned* cs, int CS, int wc, unsigned epoch, int tid,
+                                 unsigned flags_in, double& e, unsigned& idx, unsigned& flags_out)
+{
+    if (tid == 0) {
+        unsigned* slot = cs + 16 + ((epoch & 1u) * (unsigned)CS + (unsigned)wc) * kSlotDw;
+        __hip_atomic_store(slot + 0, (unsigned)__double2loint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 1, (unsigned)__double2hiint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 2, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 3, flags_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(cs, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned want = (unsigned)CS * (epoch + 1u);
+        unsigned spins = 0;
+        bool ok = true;
+        while (__hip_atomic_load(cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > kSpinLimit ||
+                __hip_atomic_load(cs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(cs + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        double be = 0.0;
+        unsigned bi = kNoMove, fl = 0;
+        if (ok) {
+            for (int w = 0; w < CS; ++w) {
+                const unsigned* sl = cs + 16 + ((epoch & 1u) * (unsigned)CS + (unsigned)w) * kSlotDw;
+                const unsigned lo = __hip_atomic_load(sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned hi = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned oi = __hip_atomic_load(sl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fl |= __hip_atomic_load(sl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double oe = __hiloint2double((int)hi, (int)lo);
+                if (better(oe, oi, be, bi)) { be = oe; bi = oi; }
+            }
+        }
+        ctl->bestE = be;
+        ctl->bestIdx = bi;
+        ctl->flags = (int)fl;
+        ctl->ambiguous = ok ? 0 : 1;        // reused as the abort flag
+    }
+    __syncthreads();
+    e = ctl->bestE;
+    idx = ctl->bestIdx;
+    flags_out = (unsigned)ctl->flags;
+    const bool ok = ctl->ambiguous == 0;
+    __syncthreads();
+    return ok;
+}
+
+constexpr unsigned kFlagStop = 1u;      // published by workgroup 0: wall-clock limit reached
+
+template <typename T, int MAXNT>
+__global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const CGeo g = p.g;
+    const int n = g.n, tid = threadIdx.x, nt = g.nt;
+    const int cluster = blockIdx.x / g.CS, wc = blockIdx.x % g.CS;
+    const int cr = wc / g.CD, cd = wc % g.CD;
+    CView<T> v;
+    v.ctl = reinterpret_cast<Ctl*>(smem);
+    size_t off = align16(sizeof(Ctl));
+    v.tour = reinterpret_cast<uint16_t*>(smem + off);
+    off += align16(sizeof(uint16_t) * (size_t)(n + 1));
+    v.Xq = reinterpret_cast<v2f*>(smem + off); off += sizeof(v2f) * 4 * (size_t)g.Qw;
+    v.Yq = reinterpret_cast<v2f*>(smem + off); off += sizeof(v2f) * 4 * (size_t)g.Qw;
+    v.Eq = reinterpret_cast<v2f*>(smem + off); off += sizeof(v2f) * 4 * (size_t)g.Qw;
+    v.RX = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * (size_t)(g.rowsw + 8));
+    v.RY = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * (size_t)(g.rowsw + 8));
+    v.RE = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * (size_t)(g.rowsw + 8));
+    T* xl = reinterpret_cast<T*>(smem + off);
+    v.rs0 = cr * g.NSw;
+    v.gp0 = cd * g.GPw;
+    v.ilo = v.rs0 * g.MS + v.gp0;
+    v.rbase = 4 * v.rs0 * g.MS;
+    Ctl* ctl = v.ctl;
+    unsigned* cs = p.csync + (size_t)cluster * (size_t)p.cstride;
+    unsigned epoch = 0;                         // barriers passed by this cluster so far
+
+    for (int64_t tk = cluster; tk < p.num_tours; tk += p.num_clusters) {
+        __syncthreads();
+        const T* X = reinterpret_cast<const T*>(p.points) + (size_t)(tk / p.tpi) * (size_t)n * 2;
+        int64_t* gt = p.tours + (size_t)tk * (size_t)(n + 1);
+        // ---- stage + validate (every workgroup of the cluster computes the same flags) -------
+        int bad = 0;
+        for (int k = tid; k <= n; k += nt) {
+            const int64_t t = gt[k];
+            if (t < 0 || t >= n) { bad |= TSP2OPT_ST_BAD_INDEX; v.tour[k] = 0; }
+            else v.tour[k] = (uint16_t)t;
+        }
+        if (tid == 0 && gt[0] != gt[n]) bad |= TSP2OPT_ST_NOT_CLOSED;
+        double mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
+        for (int k = tid; k < n; k += nt) {
+            const T x = X[2 * k], y = X[2 * k + 1];
+            if (g.xlds) { xl[2 * k] = x; xl[2 * k + 1] = y; }
+            const double dx = (double)x, dy = (double)y;
+            if (!(fabs(dx) <= 1.0e150) || !(fabs(dy) <= 1.0e150))
+                bad |= (dx != dx || dy != dy || fabs(dx) == INFINITY || fabs(dy) == INFINITY)
+                           ? TSP2OPT_ST_NONFINITE : TSP2OPT_ST_RANGE;
+            mnx = fmin(mnx, dx); mxx = fmax(mxx, dx);
+            mny = fmin(mny, dy); mxy = fmax(mxy, dy);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            mnx = fmin(mnx, __shfl_xor(mnx, o)); mxx = fmax(mxx, __shfl_xor(mxx, o));
+            mny = fmin(mny, __shfl_xor(mny, o)); mxy = fmax(mxy, __shfl_xor(mxy, o));
+            bad |= __shfl_xor(bad, o);
+        }
+        if ((tid & 63) == 0) {
+            const int w = tid >> 6;
+            ctl->redd[4 * w] = mnx; ctl->redd[4 * w + 1] = mxx;
+            ctl->redd[4 * w + 2] = mny; ctl->redd[4 * w + 3] = mxy;
+            ctl->pIdx[w] = (unsigned)bad;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < (nt >> 6); ++w) {
+                mnx = fmin(mnx, ctl->redd[4 * w]); mxx = fmax(mxx, ctl->redd[4 * w + 1]);
+                mny = fmin(mny, ctl->redd[4 * w + 2]); mxy = fmax(mxy, ctl->redd[4 * w + 3]);
+                bad |= (int)ctl->pIdx[w];
+            }
+            ctl->flags = bad;
+            ctl->cx = 0.5 * (mnx + mxx);
+            ctl->cy = 0.5 * (mny + mxy);
+            const double half = fmax(0.5 * (mxx - mnx), 0.5 * (mxy - mny));
+            int ex = 0;
+            double sc = 1.0;
+            if (half > 0.0 && half < INFINITY) { (void)frexp(half, &ex); sc = ldexp(1.0, -ex); }
+            ctl->sc = sc;
+        }
+        __syncthreads();
+        const int flags = ctl->flags;
+        v.X = g.xlds ? xl : X;
+        v.cx = ctl->cx; v.cy = ctl->cy; v.sc = ctl->sc;
+        __syncthreads();
+        if (flags != 0) {                       // invalid input: same verdict in every workgroup
+            if (wc == 0 && tid == 0) { if (p.status) p.status[tk] = flags; p.iters[tk] = 0; }
+            continue;
+        }
+        stage_c(v, g, tid, 0, n - 1, 0, n - 1);
+        __syncthreads();
+
+        // ---- improvement loop (independent termination) ------------------------------------------
+        const long long t_start = p.time_limit_ticks ? wall_clock64() : 0;
+        int it = 0, sweeps = 0, st = 0;
+        bool aborted = false;
+        for (;;) {
+            double e;
+            unsigned idx, fl = 0;
+            find_best_tile(v, g, tid, wc == 0, e, idx);
+            ++sweeps;
+            unsigned myflags = 0;
+            if (wc == 0 && p.time_limit_ticks && wall_clock64() - t_start > p.time_limit_ticks)
+                myflags |= kFlagStop;
+            if (!cluster_exchange(ctl, cs, g.CS, wc, epoch, tid, myflags, e, idx, fl)) { aborted = true; break; }
+            ++epoch;
+            if (!(e < -1.0e-6)) break;                                       // two_opt.py:40
+            const int i = (int)(idx >> 16), j = (int)(idx & 0xffffu);
+            const int h = (j - i) >> 1;
+            for (int k = tid; k < h; k += nt) {                              // two_opt.py:42
+                const uint16_t a = v.tour[i + 1 + k], b = v.tour[j - k];
+                v.tour[i + 1 + k] = b;
+                v.tour[j - k] = a;
+            }
+            __syncthreads();
+            stage_c(v, g, tid, i + 1, j, i, j);
+            __syncthreads();
+            ++it;
+            if (it >= p.max_iter) { st |= TSP2OPT_ST_CAPPED; break; }        // two_opt.py:47
+            if (fl & kFlagStop) { st |= TSP2OPT_ST_TIME; break; }            // plugin two_opt.py:63-65
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (aborted) {
+            if (wc == 0 && tid == 0 && p.status) p.status[tk] = TSP2OPT_ST_INTERNAL;
+            return;                             // cluster broken: leave the remaining tours untouched
+        }
+        if (wc == 0) {
+            for (int k = tid; k <= n; k += nt) gt[k] = (int64_t)v.tour[k];
+            if (tid == 0) {
+                p.iters[tk] = it;
+                if (p.work_sweeps) p.work_sweeps[tk] += sweeps;
+                if (p.status) p.status[tk] = st;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // coupled mode helpers
 // ------------------------------------------------------------------------------------------
 // target[g] = max over the group's own iteration counts (= the first iteration at which every
@@ -1014,8 +1478,9 @@ int dispatch_main(const Params& p, const Plan& pl, int device, hipStream_t strea
 
 // workspace layout: [0,256) control words (queue head at 0); then target[groups], flag[groups],
 // iters[num_tours], work[num_tours], status[num_tours] (each 256-byte aligned)
+constexpr size_t kCsyncBytes = 64 * 1024;   // cluster barrier words + slots (<= 256 workgroups)
 struct WsLayout {
-    size_t off_target, off_flag, off_iters, off_work, off_status, total;
+    size_t off_target, off_flag, off_iters, off_work, off_status, off_csync, total;
 };
 
 WsLayout ws_layout(int64_t num_tours, int group_size)
@@ -1029,9 +1494,90 @@ WsLayout ws_layout(int64_t num_tours, int group_size)
     w.off_iters = o; o += up((size_t)num_tours * 4 + 4);
     w.off_work = o; o += up((size_t)num_tours * 4 + 4);
     w.off_status = o; o += up((size_t)num_tours * 4 + 4);
+    w.off_csync = o; o += kCsyncBytes;
     w.total = o;
     return w;
 }
+
+struct CPlan {
+    CGeo g;
+    size_t lds;
+    bool ok;
+};
+
+// geometry of the cluster kernel for at most `cs_cap` workgroups per tour
+CPlan make_cluster_plan(int n, int dtype, int cs_cap)
+{
+    CPlan best{};
+    best.ok = false;
+    if (n < 18 || cs_cap < 2) return best;
+    const size_t tsz = dtype == TSP2OPT_DTYPE_F64 ? 8 : 4;
+    const int dn = n / 2 - 1;
+    const int GP = ((dn + 3) / 4 + 1) / 2;
+    if (GP < 1 || 8 * GP + 1 > n - 2) return best;
+    const int R = (n + 3) / 4;
+    const size_t base = align16(sizeof(Ctl)) + align16(sizeof(uint16_t) * (size_t)(n + 1));
+    const size_t xbytes = (size_t)n * 2 * tsz;
+    int cs = 1;
+    while (cs * 2 <= cs_cap && cs * 2 <= 256) cs *= 2;
+    for (; cs >= 2; cs /= 2) {
+        double best_eff = 0.0;
+        for (int cd = 1; cd <= cs && cd <= 32; cd *= 2) {
+            const int cr = cs / cd;
+            const int GPw = (GP + cd - 1) / cd;
+            const int rmw = (R + cr - 1) / cr;          // macro rows per row band
+            for (int nt : {256, 512, 640}) {            // <= 640 threads: no register spills (162 VGPRs)
+                if (n < 700 && nt != 256) continue;
+                int NSw = nt / GPw;
+                if (NSw < 1) NSw = 1;
+                if (NSw > rmw) NSw = rmw;
+                const int MS = (rmw + NSw - 1) / NSw;
+                if (MS < 4 && cs > 2) continue;         // too little work per cluster barrier
+                const int units = GPw * NSw;
+                const int passes = (units + nt - 1) / nt;
+                // useful fraction: lanes busy x rows/diagonals not duplicated
+                const double eff = (double)units / ((double)nt * passes) *
+                                   ((double)R / ((double)cr * NSw * MS)) *
+                                   ((double)GP / ((double)cd * GPw));
+                const int Qw = NSw * MS + GPw + 3;
+                const int rowsw = 4 * NSw * MS;
+                size_t lds = base + (size_t)Qw * 96 + 3 * align16(sizeof(float) * (size_t)(rowsw + 8));
+                if (lds > kLdsMax || eff <= best_eff) continue;
+                CGeo g{};
+                g.n = n; g.nt = nt; g.GP = GP; g.CS = cs; g.CR = cr; g.CD = cd;
+                g.GPw = GPw; g.NSw = NSw; g.MS = MS; g.Qw = Qw; g.rowsw = rowsw;
+                g.eps2 = dtype == TSP2OPT_DTYPE_F64 ? 2.0f * 0x1p-16f : 2.0f * 0x1p-15f;
+                g.xlds = 0;
+                if (lds + align16(xbytes) <= kLdsMax) { g.xlds = 1; lds += align16(xbytes); }
+                best.g = g; best.lds = lds; best.ok = true;
+                best_eff = eff;
+            }
+        }
+        if (best.ok) return best;
+    }
+    return best;
+}
+
+template <typename T, int MAXNT>
+int launch_cluster(CParams p, const CPlan& cp, int cus, hipStream_t stream)
+{
+    auto kern = k_two_opt_cluster<T, MAXNT>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp.lds));
+    int clusters = cus / cp.g.CS;                       // one workgroup per CU: all co-resident
+    if (clusters > p.num_tours) clusters = (int)p.num_tours;
+    if (clusters < 1) return fail(TSP2OPT_E_UNSUPPORTED, "cluster does not fit the device");
+    p.num_clusters = clusters;
+    p.cstride = ((16 + 2 * cp.g.CS * kSlotDw) + 63) & ~63;
+    if ((size_t)clusters * (size_t)p.cstride * 4 > kCsyncBytes)
+        return fail(TSP2OPT_E_UNSUPPORTED, "internal: cluster sync area too small");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(clusters * cp.g.CS)), dim3((unsigned)cp.g.nt), cp.lds,
+                       stream, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int g_cluster_mode = -1;    // -1 auto, 0 never, >= 2 force that many workgroups per tour (tests)
 
 template <typename T>
 int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* sweeps_out,
@@ -1074,8 +1620,33 @@ int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* swe
     if (num_tours == 0) return 0;
     int rc = prof_record(device, 0, stream);
     if (rc) return rc;
-    rc = dispatch_main<T>(p, pl, device, stream);
-    if (rc) return rc;
+    // few tours (or N beyond one workgroup's LDS): several workgroups per tour
+    CPlan cp{};
+    cp.ok = false;
+    if (group_size == 1 && g_cluster_mode != 0 && g_dbg_sweeps == 0) {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        int cap = (int)std::min<int64_t>(256, cus / std::max<int64_t>(1, num_tours));
+        if (g_cluster_mode >= 2) cap = std::min(g_cluster_mode, cus);
+        else if (pl.g.qclass == 0) cap = std::min(cus, 256);      // no single-workgroup fast path
+        else if (n < 700) cap = 0;                                 // small tours: not worth a barrier
+        cp = make_cluster_plan(n, dtype, cap);
+        if (cp.ok) {
+            CParams c{};
+            c.points = points; c.tours = tours; c.iters = p.iters; c.work_sweeps = p.work_sweeps;
+            c.status = p.status; c.csync = reinterpret_cast<unsigned*>(w8 + wl.off_csync);
+            c.num_tours = num_tours; c.tpi = tpi; c.max_iter = max_iter;
+            c.time_limit_ticks = p.time_limit_ticks; c.g = cp.g;
+            HIP_TRY(hipMemsetAsync(w8 + wl.off_csync, 0, kCsyncBytes, stream));
+            rc = cp.g.nt <= 512 ? launch_cluster<T, 512>(c, cp, cus, stream)
+                                : launch_cluster<T, 640>(c, cp, cus, stream);
+            if (rc) return rc;
+        }
+    }
+    if (!cp.ok) {
+        rc = dispatch_main<T>(p, pl, device, stream);
+        if (rc) return rc;
+    }
     rc = prof_record(device, 1, stream);
     if (rc) return rc;
     if (g_profile && device < kMaxDev) { g_prof[device].have_main = true; g_prof[device].have_forced = false; }
@@ -1275,6 +1846,14 @@ extern "C" int tsp2opt_debug_phase_cycles(int32_t on)
 extern "C" int tsp2opt_debug_sweep_only(int32_t sweeps)
 {
     g_dbg_sweeps = sweeps > 0 ? sweeps : 0;
+    return 0;
+}
+
+// Test/diagnostic knob: -1 automatic choice between one workgroup per tour and a cluster of
+// workgroups per tour, 0 never cluster, k >= 2 use up to k workgroups per tour whenever possible.
+extern "C" int tsp2opt_debug_cluster_mode(int32_t mode)
+{
+    g_cluster_mode = mode;
     return 0;
 }
 

@@ -126,6 +126,9 @@ def two_opt_device(points: torch.Tensor, tours: torch.Tensor, *, tours_per_insta
 def raise_on_status(status: np.ndarray) -> None:
     """Turn per-tour input errors into Python exceptions (the reference would index out of range
     or silently work on a non-closed sequence)."""
+    if (status & _lib.ST_INTERNAL).any():
+        raise _lib.Tsp2optError("multi-workgroup barrier timed out (is another kernel occupying "
+                                "the device?); tours were left untouched")
     bad = np.nonzero(status & (_lib.ST_BAD_INDEX | _lib.ST_NOT_CLOSED | _lib.ST_RANGE))[0]
     if len(bad):
         k = int(bad[0])

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_files, load_golden
+from conftest import GOLDEN_DIR as GOLDEN, golden_files, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -137,3 +137,49 @@ def test_gpu_time_limit_stops_early(amd):
     assert (st & _lib.ST_TIME).all() and (res.iterations.cpu().numpy() < 600).all()
     out = res.tours.cpu().numpy()
     assert (np.sort(out[:, :-1], axis=1) == np.arange(1000)).all()
+
+
+# ---- several workgroups per tour (cluster kernel) ------------------------------------------------
+CLUSTER_CASES = [
+    # n, tours, dtype, cap, forced workgroups per tour (0 = automatic choice)
+    (64, 3, np.float64, 5000, 2), (100, 5, np.float64, 5000, 4), (200, 2, np.float32, 5000, 8),
+    (500, 3, np.float64, 5000, 16), (500, 2, np.float64, 5000, 2), (777, 2, np.float64, 5000, 0),
+    (1000, 4, np.float64, 5000, 0), (1000, 1, np.float32, 5000, 0), (1500, 1, np.float64, 300, 32),
+    (3000, 2, np.float64, 60, 0), (5000, 1, np.float64, 40, 0),
+]
+
+
+@pytest.mark.parametrize("n,tours_n,dtype,cap,force", CLUSTER_CASES)
+def test_gpu_cluster_kernel_matches_oracle(amd, oracle, n, tours_n, dtype, cap, force):
+    from ml4tspbench_amd import _lib
+    rng = np.random.default_rng(7000 + n + force)
+    pts, tours = _random_batch(rng, tours_n, 1, n, dtype)
+    ref_out, ref_it, ref_sw = oracle.solve(pts, tours, max_iterations=cap, threads=8)
+    _lib.lib().tsp2opt_debug_cluster_mode(force if force else -1)
+    try:
+        out, iters, sweeps, lengths, status = _run(amd, pts, tours, 1, 1, cap)
+    finally:
+        _lib.lib().tsp2opt_debug_cluster_mode(-1)
+    assert (status & (15 | 64)).max(initial=0) == 0
+    assert np.array_equal(out, ref_out)
+    assert np.array_equal(iters, ref_it)
+    assert np.array_equal(sweeps, ref_sw)
+
+
+def test_gpu_cluster_kernel_goldens_and_ties(amd):
+    """Goldens through the cluster kernel, including the tie-heavy grids (exact tile sweep path)."""
+    from ml4tspbench_amd import _lib
+    names = ["g2_n100_indep_f64", "g9_grid12_indep_f64", "g9_grid8_indep_f32", "g9_n120_clustered_f64",
+             "g9_n80_offset_scaled_f64", "g7_n500_indep_f32", "g4_n1000_indep_f64", "g5_n10000_cap32_f64",
+             "g6_n50_cap7_f64", "g9_n40_duplicates_f64"]
+    _lib.lib().tsp2opt_debug_cluster_mode(4)
+    try:
+        for nm in names:
+            g = load_golden(f"{GOLDEN}/{nm}.npz")
+            pts = g["points"].astype(np.float64) if g["entry"] == "tsp_2opt" else g["points"]
+            out, iters, _, _, status = _run(amd, pts, g["tours_in"], 1, 1, g["max_iterations"])
+            assert (status & (15 | 64)).max(initial=0) == 0, nm
+            assert np.array_equal(out, g["tours_out"]), nm
+            assert np.array_equal(iters, g["iterators"]), nm
+    finally:
+        _lib.lib().tsp2opt_debug_cluster_mode(-1)
