@@ -36,6 +36,7 @@ CONFIGS = {
     "tsp100": (100, 10000, 1),
     "tsp500": (500, 128, 16),
     "tsp1000": (1000, 128, 1),
+    "tsp10000": (10000, 16, 1),
 }
 FLOP_PER_PAIR = 15.0          # 2 x (2 sub + 2 mul + add + sqrt) + 3 add/sub
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU

@@ -91,6 +91,8 @@ struct Params {
 struct Prof {                         // per-thread phase timers, only live when Params::stamps != null
     bool on;
     unsigned long long sweep, select, apply;
+    unsigned amb = 0, cands = 0;
+    unsigned long long candcyc = 0;
 };
 
 struct Ctl {                          // LDS control block (first bytes of dynamic LDS)
@@ -771,6 +773,7 @@ struct CParams {
     int max_iter;
     long long time_limit_ticks;
     int num_clusters;
+    unsigned long long* stamps;     // optional phase timers (tsp2opt_debug_phase_cycles)
     CGeo g;
 };
 
@@ -939,14 +942,17 @@ __device__ __forceinline__ bool eval_chunk_pair_c(const CView<T>& v, const CGeo&
 // best move of this workgroup's tile: e = min(0, min exact delta), idx packed; valid in all threads
 template <typename T>
 __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool first_wg, double& e,
-                               unsigned& idx)
+                               unsigned& idx, Prof& pf)
 {
     Ctl* ctl = v.ctl;
     float a1, a2;
     unsigned chunk;
+    unsigned long long t0 = 0;
+    if (pf.on) t0 = clock64();
     __builtin_amdgcn_s_setprio(0);
     filter_sweep_c(v, g, tid, a1, a2, chunk);
     __builtin_amdgcn_s_setprio(3);
+    if (pf.on) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
     const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
     const float wm = wave_min(a1);
     if (lane == 0) ctl->wmin[wv] = wm;
@@ -956,6 +962,8 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
     const float thr = m + g.eps2;
     unsigned long long cmask = __ballot(a1 <= thr);
     int amb = __ballot(a2 <= thr) != 0ull || __popcll(cmask) > 8;
+    if (pf.on) pf.cands += (unsigned)__popcll(cmask);
+    const unsigned long long tc0 = pf.on ? clock64() : 0;
     e = 0.0;
     idx = kNoMove;
     if (!amb) {
@@ -975,6 +983,7 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
         }
         wave_best(e, idx);
     }
+    if (pf.on) pf.apply += 0, pf.candcyc += clock64() - tc0;
     if (lane == 0) { ctl->pE[wv] = e; ctl->pIdx[wv] = idx; ctl->pAmb[wv] = amb; }
     __syncthreads();
     e = ctl->pE[0];
@@ -986,6 +995,7 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
         amb |= ctl->pAmb[w];
         if (better(oe, oi, e, idx)) { e = oe; idx = oi; }
     }
+    if (pf.on) { pf.amb += amb ? 1 : 0; }
     if (amb) {      // two candidates in one lane: evaluate the whole tile exactly this iteration
         __syncthreads();
         e = 0.0;
@@ -1005,12 +1015,14 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
         }
         block_best(ctl, tid, g.nt, e, idx);
     }
+    if (pf.on) pf.select += clock64() - t0;
 }
 
 // publish this workgroup's (e, idx), wait for the cluster, reduce all slots.  Returns false on
 // abort (a workgroup of the cluster is missing: spin limit hit).
 __device__ bool cluster_exchange(Ctl* ctl, unsigned* cs, int CS, int wc, unsigned epoch, int tid,
-                                 unsigned flags_in, double& e, unsigned& idx, unsigned& flags_out)
+                                 int nt, unsigned flags_in, double& e, unsigned& idx,
+                                 unsigned& flags_out)
 {
     if (tid == 0) {
         unsigned* slot = cs + 16 + ((epoch & 1u) * (unsigned)CS + (unsigned)wc) * kSlotDw;
@@ -1023,7 +1035,7 @@ __device__ bool cluster_exchange(Ctl* ctl, unsigned* cs, int CS, int wc, unsigne
         unsigned spins = 0;
         bool ok = true;
         while (__hip_atomic_load(cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
             if (++spins > kSpinLimit ||
                 __hip_atomic_load(cs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                 __hip_atomic_store(cs + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1032,29 +1044,38 @@ __device__ bool cluster_exchange(Ctl* ctl, unsigned* cs, int CS, int wc, unsigne
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        double be = 0.0;
-        unsigned bi = kNoMove, fl = 0;
-        if (ok) {
-            for (int w = 0; w < CS; ++w) {
-                const unsigned* sl = cs + 16 + ((epoch & 1u) * (unsigned)CS + (unsigned)w) * kSlotDw;
-                const unsigned lo = __hip_atomic_load(sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned hi = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned oi = __hip_atomic_load(sl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                fl |= __hip_atomic_load(sl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const double oe = __hiloint2double((int)hi, (int)lo);
-                if (better(oe, oi, be, bi)) { be = oe; bi = oi; }
-            }
-        }
-        ctl->bestE = be;
-        ctl->bestIdx = bi;
-        ctl->flags = (int)fl;
         ctl->ambiguous = ok ? 0 : 1;        // reused as the abort flag
     }
     __syncthreads();
-    e = ctl->bestE;
-    idx = ctl->bestIdx;
-    flags_out = (unsigned)ctl->flags;
     const bool ok = ctl->ambiguous == 0;
+    // slot w is read by thread w (agent-scope loads: they bypass this CU's L1), then reduced
+    e = 0.0;
+    idx = kNoMove;
+    unsigned fl = 0;
+    if (ok && tid < CS) {
+        const unsigned* sl = cs + 16 + ((epoch & 1u) * (unsigned)CS + (unsigned)tid) * kSlotDw;
+        const unsigned lo = __hip_atomic_load(sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned hi = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        idx = __hip_atomic_load(sl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fl = __hip_atomic_load(sl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        e = __hiloint2double((int)hi, (int)lo);
+    }
+    wave_best(e, idx);
+    const int anyfl = __ballot(fl != 0u) != 0ull;
+    const int nw = nt >> 6, wv = tid >> 6;
+    if ((tid & 63) == 0) { ctl->pE[wv] = e; ctl->pIdx[wv] = idx; ctl->pAmb[wv] = anyfl; }
+    __syncthreads();
+    e = ctl->pE[0];
+    idx = ctl->pIdx[0];
+    int f = ctl->pAmb[0];
+    const int nwu = (CS + 63) >> 6 < nw ? (CS + 63) >> 6 : nw;      // waves that held slots
+    for (int w = 1; w < nwu; ++w) {
+        const double oe = ctl->pE[w];
+        const unsigned oi = ctl->pIdx[w];
+        f |= ctl->pAmb[w];
+        if (better(oe, oi, e, idx)) { e = oe; idx = oi; }
+    }
+    flags_out = f ? 1u : 0u;
     __syncthreads();
     return ok;
 }
@@ -1156,16 +1177,20 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
         const long long t_start = p.time_limit_ticks ? wall_clock64() : 0;
         int it = 0, sweeps = 0, st = 0;
         bool aborted = false;
+        Prof pf{p.stamps != nullptr, 0, 0, 0};
+        unsigned long long t_x = 0, t_tour = pf.on ? clock64() : 0;
         for (;;) {
             double e;
             unsigned idx, fl = 0;
-            find_best_tile(v, g, tid, wc == 0, e, idx);
+            find_best_tile(v, g, tid, wc == 0, e, idx, pf);
             ++sweeps;
+            unsigned long long tb = pf.on ? clock64() : 0;
             unsigned myflags = 0;
             if (wc == 0 && p.time_limit_ticks && wall_clock64() - t_start > p.time_limit_ticks)
                 myflags |= kFlagStop;
-            if (!cluster_exchange(ctl, cs, g.CS, wc, epoch, tid, myflags, e, idx, fl)) { aborted = true; break; }
+            if (!cluster_exchange(ctl, cs, g.CS, wc, epoch, tid, nt, myflags, e, idx, fl)) { aborted = true; break; }
             ++epoch;
+            if (pf.on) { const unsigned long long t1 = clock64(); t_x += t1 - tb; tb = t1; }
             if (!(e < -1.0e-6)) break;                                       // two_opt.py:40
             const int i = (int)(idx >> 16), j = (int)(idx & 0xffffu);
             const int h = (j - i) >> 1;
@@ -1177,11 +1202,22 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
             __syncthreads();
             stage_c(v, g, tid, i + 1, j, i, j);
             __syncthreads();
+            if (pf.on) pf.apply += clock64() - tb;
             ++it;
             if (it >= p.max_iter) { st |= TSP2OPT_ST_CAPPED; break; }        // two_opt.py:47
             if (fl & kFlagStop) { st |= TSP2OPT_ST_TIME; break; }            // plugin two_opt.py:63-65
         }
         __builtin_amdgcn_s_setprio(0);
+        if (pf.on && tid == 0) {
+            atomicAdd(&p.stamps[0], pf.sweep);
+            atomicAdd(&p.stamps[1], pf.select);
+            atomicAdd(&p.stamps[2], pf.apply);
+            atomicAdd(&p.stamps[3], t_x);
+            atomicAdd(&p.stamps[5], (unsigned long long)pf.amb);
+            atomicAdd(&p.stamps[6], (unsigned long long)pf.cands);
+            atomicAdd(&p.stamps[7], pf.candcyc);
+            atomicAdd(&p.stamps[4], clock64() - t_tour);
+        }
         if (aborted) {
             if (wc == 0 && tid == 0 && p.status) p.status[tk] = TSP2OPT_ST_INTERNAL;
             return;                             // cluster broken: leave the remaining tours untouched
@@ -1506,7 +1542,7 @@ struct CPlan {
 };
 
 // geometry of the cluster kernel for at most `cs_cap` workgroups per tour
-CPlan make_cluster_plan(int n, int dtype, int cs_cap)
+CPlan make_cluster_plan(int n, int dtype, int cs_cap, bool smallest)
 {
     CPlan best{};
     best.ok = false;
@@ -1518,15 +1554,18 @@ CPlan make_cluster_plan(int n, int dtype, int cs_cap)
     const int R = (n + 3) / 4;
     const size_t base = align16(sizeof(Ctl)) + align16(sizeof(uint16_t) * (size_t)(n + 1));
     const size_t xbytes = (size_t)n * 2 * tsz;
-    int cs = 1;
-    while (cs * 2 <= cs_cap && cs * 2 <= 256) cs *= 2;
-    for (; cs >= 2; cs /= 2) {
-        double best_eff = 0.0;
-        for (int cd = 1; cd <= cs && cd <= 32; cd *= 2) {
-            const int cr = cs / cd;
+    // Exhaustive search over (row bands, diagonal bands, threads): minimise the modelled time of
+    // one iteration = sweep (macro steps x passes x waves per SIMD, ~0.4 us per wave macro step on a
+    // saturated SIMD) + fixed per-iteration cost (selection, reversal, cluster barrier).
+    // `smallest`: many tours, tiling only for LDS capacity -> maximise work per workgroup instead.
+    double best_cost = 1e300;
+    for (int cr = 1; cr <= cs_cap; ++cr) {
+        for (int cd = 1; cr * cd <= cs_cap; ++cd) {
+            const int cs = cr * cd;
+            if (cs < 2 || cd > GP || cr > R) continue;
             const int GPw = (GP + cd - 1) / cd;
             const int rmw = (R + cr - 1) / cr;          // macro rows per row band
-            for (int nt : {256, 512, 640}) {            // <= 640 threads: no register spills (162 VGPRs)
+            for (int nt : {256, 512, 768}) {            // <= 768 threads: 3 waves/SIMD, no spills
                 if (n < 700 && nt != 256) continue;
                 int NSw = nt / GPw;
                 if (NSw < 1) NSw = 1;
@@ -1535,14 +1574,13 @@ CPlan make_cluster_plan(int n, int dtype, int cs_cap)
                 if (MS < 4 && cs > 2) continue;         // too little work per cluster barrier
                 const int units = GPw * NSw;
                 const int passes = (units + nt - 1) / nt;
-                // useful fraction: lanes busy x rows/diagonals not duplicated
-                const double eff = (double)units / ((double)nt * passes) *
-                                   ((double)R / ((double)cr * NSw * MS)) *
-                                   ((double)GP / ((double)cd * GPw));
+                const int wps = (nt / 64 + 3) / 4;      // waves per SIMD
+                const double t_iter = 0.4 * MS * passes * wps + 12.0 + 0.15 * cs;
+                const double cost = smallest ? t_iter * cs : t_iter;    // total WG-time vs latency
                 const int Qw = NSw * MS + GPw + 3;
                 const int rowsw = 4 * NSw * MS;
                 size_t lds = base + (size_t)Qw * 96 + 3 * align16(sizeof(float) * (size_t)(rowsw + 8));
-                if (lds > kLdsMax || eff <= best_eff) continue;
+                if (lds > kLdsMax || cost >= best_cost) continue;
                 CGeo g{};
                 g.n = n; g.nt = nt; g.GP = GP; g.CS = cs; g.CR = cr; g.CD = cd;
                 g.GPw = GPw; g.NSw = NSw; g.MS = MS; g.Qw = Qw; g.rowsw = rowsw;
@@ -1550,10 +1588,9 @@ CPlan make_cluster_plan(int n, int dtype, int cs_cap)
                 g.xlds = 0;
                 if (lds + align16(xbytes) <= kLdsMax) { g.xlds = 1; lds += align16(xbytes); }
                 best.g = g; best.lds = lds; best.ok = true;
-                best_eff = eff;
+                best_cost = cost;
             }
         }
-        if (best.ok) return best;
     }
     return best;
 }
@@ -1626,20 +1663,22 @@ int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* swe
     if (group_size == 1 && g_cluster_mode != 0 && g_dbg_sweeps == 0) {
         int cus = 0;
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-        int cap = (int)std::min<int64_t>(256, cus / std::max<int64_t>(1, num_tours));
+        int cap = (int)std::min<int64_t>(64, cus / std::max<int64_t>(1, num_tours));
+        bool smallest = false;
         if (g_cluster_mode >= 2) cap = std::min(g_cluster_mode, cus);
-        else if (pl.g.qclass == 0) cap = std::min(cus, 256);      // no single-workgroup fast path
-        else if (n < 700) cap = 0;                                 // small tours: not worth a barrier
-        cp = make_cluster_plan(n, dtype, cap);
+        else if (pl.g.qclass == 0 && cap < 2) { cap = 64; smallest = true; }   // tiling for LDS only
+        else if (pl.g.qclass != 0 && n < 700) cap = 0;             // small tours: not worth a barrier
+        cp = make_cluster_plan(n, dtype, cap, smallest);
         if (cp.ok) {
             CParams c{};
             c.points = points; c.tours = tours; c.iters = p.iters; c.work_sweeps = p.work_sweeps;
             c.status = p.status; c.csync = reinterpret_cast<unsigned*>(w8 + wl.off_csync);
             c.num_tours = num_tours; c.tpi = tpi; c.max_iter = max_iter;
             c.time_limit_ticks = p.time_limit_ticks; c.g = cp.g;
+            c.stamps = p.stamps;
             HIP_TRY(hipMemsetAsync(w8 + wl.off_csync, 0, kCsyncBytes, stream));
             rc = cp.g.nt <= 512 ? launch_cluster<T, 512>(c, cp, cus, stream)
-                                : launch_cluster<T, 640>(c, cp, cus, stream);
+                                : launch_cluster<T, 768>(c, cp, cus, stream);
             if (rc) return rc;
         }
     }

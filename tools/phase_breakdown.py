@@ -12,25 +12,29 @@ from ml4tspbench_amd import _lib, two_opt
 cfg = sys.argv[1] if len(sys.argv) > 1 else "tsp500"
 dt = np.float64 if (len(sys.argv) < 3 or sys.argv[2] == "f64") else np.float32
 pts, tours, tpi = bench.make_batch(cfg, 1234, dt)
+CAP = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
 dev = torch.device("cuda", 0)
 d_pts, d_tours = torch.from_numpy(pts).to(dev), torch.from_numpy(tours).to(dev)
 L = _lib.lib()
-amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi)
+amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi, max_iterations=CAP)
 torch.cuda.synchronize()
 L.tsp2opt_debug_phase_cycles(1)
 t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
 t0.record()
-res = amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi)
+res = amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi, max_iterations=CAP)
 t1.record(); torch.cuda.synchronize()
 ws = list(two_opt._workspaces.values())[0]
-st = ws[64:104].cpu().numpy().view(np.uint64)
-names = ["sweep", "select", "apply", "stage", "tour_total"]
+st = ws[64:128].cpu().numpy().view(np.uint64)
+print('amb events:', int(st[5]), 'wave0 cands', int(st[6]), 'wave0 cand cycles', int(st[7]), 'sweeps', int(res.sweeps.sum().item()))
+names = ["sweep", "select", "apply", "stage/exchange", "tour_total"]
 tot = float(st[4])
 sw = int(res.sweeps.sum().item())
 print(f"{cfg} {dt.__name__}: {t0.elapsed_time(t1):.2f} ms (stamped build), plan={_lib.plan(pts.shape[1], 1 if dt==np.float64 else 0, 0)}")
 for n, v in zip(names, st):
     print(f"  {n:10s} {int(v):>16d} cycles  {100*float(v)/tot:6.2f} %   per sweep: {float(v)/sw:9.1f}")
 L.tsp2opt_debug_phase_cycles(0)
+if pts.shape[1] > 2500 or len(tours) < 200:
+    sys.exit(0)
 # hot loop in isolation
 K = 600
 L.tsp2opt_debug_sweep_only(K)
