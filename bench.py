@@ -182,11 +182,18 @@ def main():
         forced_ms = float(np.mean([k[1] for k in kern_ms])) if kern_ms else None
         my_pairs = float(sweeps.sum().item()) * pairs
         roof = None
+        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes of this
+        try:                    # same command (tools/pmc_passes.sh); counters cannot be read in-process
+            if args.config == "tsp500" and args.mode == "independent" and args.dtype == "f64":
+                with open(os.path.join(ROOT, "profiles", "r01_tsp500_pmc_summary.json")) as fh:
+                    traffic = [v for k, v in json.load(fh)["derived"].items() if k.startswith("hbm_bytes")][0]
+        except Exception:
+            traffic = None
         if main_ms:
             kernel_ms = main_ms + (forced_ms or 0.0)
             ach = my_pairs * FLOP_PER_PAIR / (kernel_ms * 1e-3) / 1e12
             roof = {"bound": "valu", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
                     "kernel": "k_two_opt", "kernel_ms": kernel_ms,
                     "note": "algorithmic 15 FLOP per pair-delta / HIP-event duration of the persistent "
                             "kernel (rank 0); VALU-bound, HBM traffic is O(N) per tour"}
