@@ -65,6 +65,7 @@ struct Geo {                          // launch geometry of the filter sweep (ho
     int NS;                           // row segments
     int MS;                           // macro steps (4 rows) per segment
     int xlds;                         // exact coordinates cached in LDS
+    int W;                            // window positions actually read (multiple of 4, <= 4*Q)
     float eps2;                       // 2*eps of the filter, in scaled units
 };
 
@@ -394,10 +395,32 @@ __device__ __forceinline__ void eval_chunk_pair(const View<T>& v, const Geo& g, 
     idx = ((unsigned)i << 16) | (unsigned)j;
 }
 
+// fp32 (filter) value of pair `pr` of macro step `id`, recomputed from the LDS window exactly as the
+// sweep computes it, with the pair's packed index
+template <int Q, typename T>
+__device__ __forceinline__ void filter_chunk_pair(const View<T>& v, const Geo& g, unsigned id, int pr,
+                                                  float& d, unsigned& idx)
+{
+    const int u = (int)(id / (unsigned)g.MS), m = (int)(id % (unsigned)g.MS);
+    const int gi = u % g.GP + (pr >> 4) * g.GP, s = u / g.GP;
+    const int a = (pr >> 2) & 3, q = pr & 3;
+    const int rw = 4 * (s * g.MS + m) + a, cw = rw + 2 + 4 * gi + q;    // window positions
+    const int sr = slot<Q>(rw), sr1 = slot<Q>(rw + 1), sc = slot<Q>(cw), sc1 = slot<Q>(cw + 1);
+    const float d0 = dist32(v.Xq[sr].x, v.Yq[sr].x, v.Xq[sc].x, v.Yq[sc].x);
+    const float d1 = dist32(v.Xq[sr1].x, v.Yq[sr1].x, v.Xq[sc1].x, v.Yq[sc1].x);
+    d = ((d0 + d1) - v.Eq[sc].x) - v.Eq[sr].x;
+    const int r = rw % g.n, c = cw % g.n;
+    const int i = r < c ? r : c, j = r < c ? c : r;
+    idx = ((unsigned)i << 16) | (unsigned)j;
+}
+
 // One full argmin (the reference's per-tour torch.min / torch.argmin, two_opt.py:35-38).
 // Returns in every thread: e = min(0, min valid delta), idx = packed (i,j) or kNoMove.
+// `need_exact_sign`: the caller needs the exact sign of a non-improving minimum (coupled-mode
+// continuation); otherwise a minimum proven >= -1e-6 by the filter alone ends the search.
 template <typename T, int Q>
-__device__ void find_best(const View<T>& v, const Geo& g, int tid, double& e, unsigned& idx, Prof& pf)
+__device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exact_sign, double& e,
+                          unsigned& idx, Prof& pf)
 {
     Ctl* ctl = v.ctl;
     unsigned long long t0 = 0;
@@ -422,15 +445,93 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, double& e, un
         float m = ctl->wmin[0];
         for (int w = 1; w < nw; ++w) m = fminf(m, ctl->wmin[w]);
         const float thr = m + g.eps2;
-        // each wave re-evaluates its own candidate macro steps exactly (lanes 0..31 = the 32 pairs)
-        unsigned long long cmask = __ballot(a1 <= thr);
-        int amb = __ballot(a2 <= thr) != 0ull || __popcll(cmask) > 8;
+        const unsigned long long cmask0 = __ballot(a1 <= thr);
+        int amb = __ballot(a2 <= thr) != 0ull || __popcll(cmask0) > 8;
+
+        // ---- stage 1, fp32 only.  Every pair whose exact delta can be the argmin has a filter
+        // value <= m + 2 eps and sits in a candidate macro step.  Re-evaluate those steps pair by
+        // pair (lanes 0..31) in fp32: if exactly ONE pair of the whole tour is inside the window it
+        // IS the reference's argmin, and if its value is below -1e-6 by more than eps the move is
+        // certain without any exact arithmetic.  Likewise a window that lies above -1e-6 + eps
+        // proves convergence.  Anything else falls through to the exact stage.
+        const float thr_scale = (float)(1.0e-6 * ctl->sc);
+        const float eps = 0.625f * g.eps2;                  // eps2 = 2 eps; 25 % extra margin
+        float fd = INFINITY;
+        unsigned fidx = 0xffffffffu;
+        bool multi = false;
+        if (!amb) {
+            unsigned long long cm = cmask0;
+            while (cm) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)cm) - 1);
+                cm &= cm - 1;
+                const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)chunk, src);
+                if (lane < 32) {
+                    float d;
+                    unsigned di;
+                    filter_chunk_pair<Q>(v, g, id, lane, d, di);
+                    if (d <= thr) {
+                        multi = multi || (fidx != 0xffffffffu && fidx != di);
+                        if (d < fd || (d == fd && di < fidx)) { fd = d; fidx = di; }
+                    }
+                }
+            }
+            if (tid == 32) {    // the pair (0, n-1): cyclically adjacent, not on any walked diagonal
+                const int n = g.n;
+                const int s0 = slot<Q>(0), s1 = slot<Q>(1), sn1 = slot<Q>(n - 1), sn = slot<Q>(n);
+                const float d0 = dist32(v.Xq[s0].x, v.Yq[s0].x, v.Xq[sn1].x, v.Yq[sn1].x);
+                const float d1 = dist32(v.Xq[s1].x, v.Yq[s1].x, v.Xq[sn].x, v.Yq[sn].x);
+                const float d = ((d0 + d1) - v.Eq[sn1].x) - v.Eq[s0].x;
+                if (d <= thr) { fd = d; fidx = (unsigned)(n - 1); }
+            }
+        }
+        double wd = (double)fd;
+        unsigned widx = fidx;
+        wave_best(wd, widx);
+        const bool wother = __ballot(multi || (fidx != 0xffffffffu && fidx != widx)) != 0ull;
+        if (lane == 0) {
+            ctl->pE[wv] = wd;
+            ctl->pIdx[wv] = widx;
+            ctl->pAmb[wv] = amb | (wother ? 2 : 0);
+        }
+        __syncthreads();
+        double bd = ctl->pE[0];
+        unsigned bi = ctl->pIdx[0];
+        int fl = ctl->pAmb[0];
+        bool unique = true;
+        for (int w = 1; w < nw; ++w) {
+            const double od = ctl->pE[w];
+            const unsigned oi = ctl->pIdx[w];
+            fl |= ctl->pAmb[w];
+            if (oi != 0xffffffffu && bi != 0xffffffffu && oi != bi) unique = false;
+            if (better(od, oi, bd, bi)) { bd = od; bi = oi; }
+        }
+        amb = fl & 1;
+        unique = unique && !(fl & 2) && bi != 0xffffffffu;
+        if (!amb) {
+            if (unique && (float)bd < -thr_scale - eps) {           // certain improving move
+                e = ((double)(float)bd + (double)eps) / ctl->sc;     // an upper bound, < -1e-6
+                idx = bi;
+                if (pf.on) pf.select += clock64() - t0;
+                return;
+            }
+            if (!need_exact_sign && m > -thr_scale + eps && (bi == 0xffffffffu || (float)bd > -thr_scale + eps)) {
+                e = 0.0;                                            // proven: no delta below -1e-6
+                idx = kNoMove;
+                if (pf.on) pf.select += clock64() - t0;
+                return;
+            }
+        }
+        __syncthreads();        // partials are rewritten below
+
+        // ---- stage 2, exact: each wave re-evaluates its candidate macro steps in the reference's
+        // dtype and operation order (lanes 0..31 = the 32 pairs)
         e = 0.0;
         idx = kNoMove;
         if (!amb) {
-            while (cmask) {
-                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)cmask) - 1);
-                cmask &= cmask - 1;
+            unsigned long long cm = cmask0;
+            while (cm) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)cm) - 1);
+                cm &= cm - 1;
                 const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)chunk, src);
                 if (lane < 32) {
                     double d;
@@ -439,21 +540,19 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, double& e, un
                     if (better(d, di, e, idx)) { e = d; idx = di; }
                 }
             }
-            if (tid == 32) {    // the pair (0, n-1): cyclically adjacent, not on any walked diagonal
+            if (tid == 32) {
                 const double d = exact_delta(v, 0, g.n - 1);
                 if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
             }
             wave_best(e, idx);
         }
-        if (lane == 0) { ctl->pE[wv] = e; ctl->pIdx[wv] = idx; ctl->pAmb[wv] = amb; }
+        if (lane == 0) { ctl->pE[wv] = e; ctl->pIdx[wv] = idx; }
         __syncthreads();
         e = ctl->pE[0];
         idx = ctl->pIdx[0];
-        amb = ctl->pAmb[0];
         for (int w = 1; w < nw; ++w) {
             const double oe = ctl->pE[w];
             const unsigned oi = ctl->pIdx[w];
-            amb |= ctl->pAmb[w];
             if (better(oe, oi, e, idx)) { e = oe; idx = oi; }
         }
         if (amb) {      // a lane holds two macro steps inside the window: exact sweep this iteration
@@ -470,7 +569,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, double& e, un
 template <int Q, typename T>
 __device__ __forceinline__ void put_xy(const View<T>& v, const Geo& g, int p, float x, float y)
 {
-    for (int w = p; w < 4 * Q; w += g.n) {
+    for (int w = p; w < g.W; w += g.n) {
         const int s = slot<Q>(w);
         v.Xq[s].x = x;
         v.Yq[s].x = y;
@@ -485,7 +584,7 @@ __device__ __forceinline__ void put_xy(const View<T>& v, const Geo& g, int p, fl
 template <int Q, typename T>
 __device__ __forceinline__ void put_e(const View<T>& v, const Geo& g, int p, float e)
 {
-    for (int w = p; w < 4 * Q; w += g.n) {
+    for (int w = p; w < g.W; w += g.n) {
         const int s = slot<Q>(w);
         v.Eq[s].x = e;
         if (w >= 4 * g.GP) v.Eq[s - g.GP].y = e;
@@ -684,7 +783,7 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
         for (;;) {
             const bool check_only = forced && it >= target;
             if (check_only && target >= p.max_iter) break;
-            find_best<T, Q>(v, g, tid, e, idx, pf);
+            find_best<T, Q>(v, g, tid, forced, e, idx, pf);
             ++sweeps;
             const bool active = e < -1.0e-6;
             bool stop_after = false;
@@ -1460,6 +1559,7 @@ Plan make_plan(int n, int dtype)
             for (int qc : kQClasses) {
                 if (qc >= q && base + (size_t)qc * 96 <= kLdsMax) {
                     g.qclass = qc; g.GP = GP; g.G = G; g.NS = NS; g.MS = MS;
+                    g.W = (W + 3) & ~3;
                     pl.S = 4 * MS; pl.W = W;
                     break;
                 }
