@@ -102,6 +102,24 @@ int tsp2opt_tour_lengths(const void* points, const int64_t* tours, double* lengt
                          int32_t device, void* hip_stream);
 
 /*
+ * tsp2opt_evaluate -- the step right after the local search, for a whole batch on the device:
+ *   valid_out[k]  bit 0: tour k's first n entries are a permutation of 0..n-1
+ *                        (ML4TSPNARLocalSearch.is_valid_tour, nar/local_search/base.py:31-32,67-70;
+ *                         `assert sorted(tour[:-1]) == range(N)`, models/modelzoo/gnn/tsp_gnn.py:214-215)
+ *                 bit 1: tour[n] == 0 (base.py:71);   bit 2: tour[n] == tour[0]
+ *   lengths_out[k] closed-tour length in double (TSPEvaluator.evaluate, utils/evaluator.py:5-13)
+ *   best_index_out[i] / best_length_out[i] (may be NULL): first minimal-length tour among instance
+ *                 i's tours_per_instance tours, as a global tour index (np.min over the parallel
+ *                 samples, tsp_gnn.py:220-221)
+ * Entries outside [0, n) make the tour invalid and its length NaN; nothing is dereferenced out of
+ * range.
+ */
+int tsp2opt_evaluate(const void* points, const int64_t* tours, double* lengths_out,
+                     int32_t* valid_out, int64_t* best_index_out, double* best_length_out,
+                     int64_t num_tours, int32_t n, int32_t tours_per_instance, int32_t dtype,
+                     int32_t device, void* hip_stream);
+
+/*
  * tsp2opt_sqrt_check -- numerics self-test used by the GPU test-suite: out[k] = sqrt(in[k])
  * computed with the exact device routine the delta evaluation uses (dtype as above).  Lets the
  * tests prove 0-ulp agreement with the host's correctly rounded sqrt (SURVEY.md hard part b).

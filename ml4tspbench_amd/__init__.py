@@ -4,14 +4,16 @@
 Only the hot path lives here: the HIP kernels + C ABI (``csrc/``, ``libtsp2opt_hip.so``) and the
 host-side mirror of the reference interfaces.
 """
-from .two_opt import batched_two_opt_torch, tsp_2opt, two_opt_device, TwoOptResult  # noqa: F401
+from .two_opt import (  # noqa: F401
+    batched_two_opt_torch, tsp_2opt, two_opt_device, TwoOptResult, evaluate_tours, EvalResult,
+)
 from .local_search import (  # noqa: F401
     ML4TSPNARLocalSearch, ML4TSPNARTwoOpt, ML4TSPARLocalSearch, ML4TSPARTwoOpt,
     get_local_search_by_name, get_local_search_func, LOCAL_SEARCH_CLASS,
 )
 
 __all__ = [
-    "batched_two_opt_torch", "tsp_2opt", "two_opt_device", "TwoOptResult",
+    "batched_two_opt_torch", "tsp_2opt", "two_opt_device", "TwoOptResult", "evaluate_tours", "EvalResult",
     "ML4TSPNARLocalSearch", "ML4TSPNARTwoOpt", "ML4TSPARLocalSearch", "ML4TSPARTwoOpt",
     "get_local_search_by_name", "get_local_search_func", "LOCAL_SEARCH_CLASS",
 ]

@@ -522,6 +522,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
             }
         }
         __syncthreads();        // partials are rewritten below
+        if (pf.on) { pf.cands += 1; pf.amb += amb ? 1 : 0; }
 
         // ---- stage 2, exact: each wave re-evaluates its candidate macro steps in the reference's
         // dtype and operation order (lanes 0..31 = the 32 pairs)
@@ -830,6 +831,8 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
                 atomicAdd(&p.stamps[1], pf.select);
                 atomicAdd(&p.stamps[2], pf.apply);
                 atomicAdd(&p.stamps[4], clock64() - t_tour);
+                atomicAdd(&p.stamps[5], (unsigned long long)pf.amb);
+                atomicAdd(&p.stamps[6], (unsigned long long)pf.cands);
             }
         }
     }
@@ -1460,6 +1463,69 @@ __global__ void k_lengths(const T* points, const int64_t* tours, double* out, in
     if (lane == 0) out[tk] = s;
 }
 
+// Validation + length of every tour, one wave per tour (replaces the per-tour Python checks of
+// nar/local_search/base.py:67-72 and the per-edge loop of utils/evaluator.py:5-13).
+//   valid bit 0: first n entries are a permutation of 0..n-1   (base.py:31-32 is_valid_tour)
+//   valid bit 1: tour[n] == 0                                   (base.py:71)
+//   valid bit 2: tour[n] == tour[0]
+template <typename T>
+__global__ void k_evaluate(const T* points, const int64_t* tours, double* lengths, int32_t* valid,
+                           int64_t num_tours, int n, int tpi, int words)
+{
+    extern __shared__ unsigned seen_all[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t tk = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    if (tk >= num_tours) return;                     // whole wave leaves together
+    unsigned* seen = seen_all + (size_t)wv * words;
+    const T* X = points + (size_t)(tk / tpi) * (size_t)n * 2;
+    const int64_t* t = tours + (size_t)tk * (size_t)(n + 1);
+    for (int k = lane; k < words; k += 64) seen[k] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    int bad = 0;
+    double s = 0.0;
+    for (int k = lane; k < n; k += 64) {
+        const int64_t a = t[k], b = t[k + 1];
+        const bool ain = a >= 0 && a < n, bin = b >= 0 && b < n;
+        if (!ain) bad = 1;
+        else {
+            const unsigned bit = 1u << (a & 31);
+            if (atomicOr(&seen[a >> 5], bit) & bit) bad = 1;      // duplicate
+        }
+        if (ain && bin) {
+            const double dx = (double)X[2 * a] - (double)X[2 * b];
+            const double dy = (double)X[2 * a + 1] - (double)X[2 * b + 1];
+            s += __builtin_sqrt(dx * dx + dy * dy);
+        } else s = NAN;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const bool anybad = __ballot(bad) != 0ull;
+    if (lane == 0) {
+        int v = anybad ? 0 : 1;
+        if (t[n] == 0) v |= 2;
+        if (t[n] == t[0]) v |= 4;
+        if (lengths) lengths[tk] = s;
+        if (valid) valid[tk] = v;
+    }
+}
+
+// best tour of every instance: first index of the minimal length among its tours
+// (tsp_gnn.py:220-221 np.min over the parallel samples; narsolver keeps the per-instance best)
+__global__ void k_best_of(const double* lengths, int64_t* best_index, double* best_length,
+                          int64_t num_instances, int tpi)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_instances) return;
+    int64_t bk = i * tpi;
+    double bl = lengths[bk];
+    for (int k = 1; k < tpi; ++k) {
+        const double l = lengths[i * tpi + k];
+        if (l < bl || (bl != bl && l == l)) { bl = l; bk = i * tpi + k; }
+    }
+    if (best_index) best_index[i] = bk;
+    if (best_length) best_length[i] = bl;
+}
+
 template <typename T>
 __global__ void k_sqrt_check(const T* in, T* out, int64_t count)
 {
@@ -1919,6 +1985,42 @@ extern "C" int tsp2opt_tour_lengths(const void* points, const int64_t* tours, do
     else
         return fail(TSP2OPT_E_ARG, "bad dtype");
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int tsp2opt_evaluate(const void* points, const int64_t* tours, double* lengths_out,
+                                int32_t* valid_out, int64_t* best_index_out, double* best_length_out,
+                                int64_t num_tours, int32_t n, int32_t tours_per_instance,
+                                int32_t dtype, int32_t device, void* hip_stream)
+{
+    if (num_tours < 0 || n < 1 || n > TSP2OPT_MAX_N || tours_per_instance < 1)
+        return fail(TSP2OPT_E_ARG, "bad size");
+    if (num_tours % tours_per_instance != 0) return fail(TSP2OPT_E_ARG, "num_tours % tours_per_instance != 0");
+    if (num_tours == 0) return 0;
+    if (!points || !tours || !lengths_out) return fail(TSP2OPT_E_ARG, "null pointer");
+    if (dtype != TSP2OPT_DTYPE_F32 && dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(TSP2OPT_E_HIP, "hipSetDevice failed");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const int words = (n + 31) / 32;
+    const int wpb = words * 4 * 4 <= 48 * 1024 ? 4 : 1;             // waves (tours) per block
+    const unsigned grid = (unsigned)((num_tours + wpb - 1) / wpb);
+    const size_t lds = (size_t)wpb * words * 4;
+    if (dtype == TSP2OPT_DTYPE_F64)
+        hipLaunchKernelGGL(k_evaluate<double>, dim3(grid), dim3(64 * wpb), lds, stream,
+                           static_cast<const double*>(points), tours, lengths_out, valid_out, num_tours,
+                           n, tours_per_instance, words);
+    else
+        hipLaunchKernelGGL(k_evaluate<float>, dim3(grid), dim3(64 * wpb), lds, stream,
+                           static_cast<const float*>(points), tours, lengths_out, valid_out, num_tours,
+                           n, tours_per_instance, words);
+    HIP_TRY(hipGetLastError());
+    if (best_index_out || best_length_out) {
+        const int64_t inst = num_tours / tours_per_instance;
+        hipLaunchKernelGGL(k_best_of, dim3((unsigned)((inst + 255) / 256)), dim3(256), 0, stream,
+                           lengths_out, best_index_out, best_length_out, inst, tours_per_instance);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .two_opt import raise_on_status, tsp_2opt, two_opt_device, _resolve_device
+from .two_opt import evaluate_tours, raise_on_status, tsp_2opt, two_opt_device, _resolve_device
 
 
 def to_numpy(x):
@@ -119,6 +119,7 @@ class ML4TSPNARTwoOpt(ML4TSPNARLocalSearch):
         super().__init__(time_limit=time_limit)
         self.max_iterations_2opt = max_iterations_2opt
         self.last_result = None          # TwoOptResult of the latest batched call (device tensors)
+        self.last_eval = None            # EvalResult (validity, lengths, best tour per instance)
 
     def _device(self, *tensors) -> torch.device:
         for t in tensors:
@@ -155,11 +156,21 @@ class ML4TSPNARTwoOpt(ML4TSPNARLocalSearch):
                              group_size=1, max_iterations=self.max_iterations_2opt,
                              time_limit=self.time_limit, want_lengths=True)
         self.last_result = res
+        # validity (base.py:67-72), lengths and the best tour per instance, still on the device
+        ev = evaluate_tours(p.to(dev), res.tours, tours_per_instance=per_tours_num * per_heatmap_num) \
+            if t.shape[0] == p.shape[0] * per_tours_num * per_heatmap_num else None
+        self.last_eval = ev
         solved_tours = res.tours.cpu().numpy()
         raise_on_status(res.status.cpu().numpy())
         # kept like the reference: numpy copies of the inputs as attributes
         self.tours, self.points, self.heatmap = to_numpy(t), to_numpy(p), to_numpy(heatmap)
-        self._validate(solved_tours)
+        if ev is None:
+            self._validate(solved_tours)
+        else:
+            ok = (ev.valid.cpu().numpy() & 3) == 3          # permutation and ends at node 0
+            if not ok.all():
+                tour = solved_tours[int(np.nonzero(~ok)[0][0])]
+                raise ValueError(f"The tour {tour} is not valid!")
         return solved_tours
 
     def _local_search(self, tour: np.ndarray, points: np.ndarray, heatmap: np.ndarray = None) -> np.ndarray:

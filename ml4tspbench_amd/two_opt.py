@@ -123,6 +123,48 @@ def two_opt_device(points: torch.Tensor, tours: torch.Tensor, *, tours_per_insta
     return TwoOptResult(out, iters, sweeps, lengths, status)
 
 
+@dataclass
+class EvalResult:
+    """Device-resident validation / evaluation of a batch of tours (tsp2opt_evaluate)."""
+    lengths: torch.Tensor       # (T,) float64 closed-tour length (NaN for out-of-range entries)
+    valid: torch.Tensor         # (T,) int32   bit0 permutation, bit1 ends at node 0, bit2 closed
+    best_index: torch.Tensor    # (I,) int64   first minimal-length tour of each instance (global index)
+    best_length: torch.Tensor   # (I,) float64
+
+
+def evaluate_tours(points: torch.Tensor, tours: torch.Tensor, *, tours_per_instance: int = 1) -> EvalResult:
+    """Validity flags, lengths and the best tour per instance, all on the device.
+
+    Replaces, for a whole batch, the reference's per-tour Python checks
+    (``nar/local_search/base.py:67-72``, ``tsp_gnn.py:214-215``) and per-edge cost loop
+    (``utils/evaluator.py:5-13``, ``tsp_gnn.py:218-221``).
+    """
+    if points.device.type != "cuda" or tours.device != points.device:
+        raise ValueError("points and tours must live on the same HIP device")
+    if points.dim() == 2:
+        points = points.unsqueeze(0)
+    if tours.dim() == 1:
+        tours = tours.unsqueeze(0)
+    n = points.shape[1]
+    T = tours.shape[0]
+    if tours.shape[1] != n + 1 or T != points.shape[0] * tours_per_instance:
+        raise ValueError("expected points (I, N, 2) and tours (I * tours_per_instance, N+1)")
+    dev = points.device
+    points = points.contiguous()
+    tours = tours.to(torch.int64).contiguous()
+    inst = T // tours_per_instance
+    lengths = torch.empty(T, dtype=torch.float64, device=dev)
+    valid = torch.empty(T, dtype=torch.int32, device=dev)
+    best_i = torch.empty(inst, dtype=torch.int64, device=dev)
+    best_l = torch.empty(inst, dtype=torch.float64, device=dev)
+    rc = _lib.lib().tsp2opt_evaluate(points.data_ptr(), tours.data_ptr(), lengths.data_ptr(),
+                                     valid.data_ptr(), best_i.data_ptr(), best_l.data_ptr(), T, n,
+                                     int(tours_per_instance), _dtype_code(points.dtype), dev.index,
+                                     torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "tsp2opt_evaluate")
+    return EvalResult(lengths, valid, best_i, best_l)
+
+
 def raise_on_status(status: np.ndarray) -> None:
     """Turn per-tour input errors into Python exceptions (the reference would index out of range
     or silently work on a non-closed sequence)."""

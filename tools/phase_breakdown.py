@@ -25,7 +25,7 @@ res = amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi, max_iterations=
 t1.record(); torch.cuda.synchronize()
 ws = list(two_opt._workspaces.values())[0]
 st = ws[64:128].cpu().numpy().view(np.uint64)
-print('amb events:', int(st[5]), 'wave0 cands', int(st[6]), 'wave0 cand cycles', int(st[7]), 'sweeps', int(res.sweeps.sum().item()))
+print('amb events:', int(st[5]), 'exact-stage runs (single-WG) / wave0 cands (cluster)', int(st[6]), 'sweeps', int(res.sweeps.sum().item()))
 names = ["sweep", "select", "apply", "stage/exchange", "tour_total"]
 tot = float(st[4])
 sw = int(res.sweeps.sum().item())
