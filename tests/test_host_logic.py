@@ -87,3 +87,26 @@ def test_partition_is_contiguous_and_balanced():
             sizes = [b - a for a, b in blocks]
             assert all(blocks[k][1] == blocks[k + 1][0] for k in range(world - 1))
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_txt_format_round_trip(tmp_path):
+    """Dataset text format of the reference (generate.py:147-153, solvers/solver.py:51-78,115-138)."""
+    from ml4tspbench_amd.io import read_txt, write_txt
+    rng = np.random.default_rng(2)
+    pts = rng.random((3, 6, 2))
+    tours = np.array([np.concatenate([[0], rng.permutation(np.arange(1, 6)), [0]]) for _ in range(3)])
+    f = str(tmp_path / "tsp6.txt")
+    write_txt(f, pts, tours)
+    first = open(f).readline().strip()
+    # literal layout: "x0 y0 x1 y1 ... output t0+1 ... t0+1"
+    assert first.startswith(f"{pts[0, 0, 0]} {pts[0, 0, 1]} {pts[0, 1, 0]}")
+    assert first.split(" output ")[1].split(" ")[0] == "1" and first.endswith(" 1")
+    p2, t2 = read_txt(f)
+    assert np.array_equal(p2, pts) and np.array_equal(t2, tours)     # repr(float) round-trips exactly
+    # a file without tours
+    with open(f, "w") as fh:
+        fh.write("0.1 0.2 0.3 0.4 0.5 0.6\n")
+    p3, t3 = read_txt(f)
+    assert p3.shape == (1, 3, 2) and t3 is None
+    with pytest.raises(AssertionError):
+        read_txt(str(tmp_path / "x.tsp"))
