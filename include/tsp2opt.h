@@ -120,6 +120,25 @@ int tsp2opt_evaluate(const void* points, const int64_t* tours, double* lengths_o
                      int32_t device, void* hip_stream);
 
 /*
+ * tsp2opt_greedy_decode -- greedy edge-merge decoder, the step right before the local search.
+ * Replaces tsp_greedy (search/greedy_search.py:19-74) + merge_cython
+ * (search/cython_merge/sources/cython_merge.pyx:19-120) for a whole batch of heat maps:
+ *   heat      (num_maps, n, n) float or double, dense (the reference densifies sparse heat maps
+ *             first, greedy_search.py:41-47); NOT symmetrised (A + A^T is formed here, :36-38)
+ *   points    (num_instances, n, 2) double (the reference casts to double, greedy_search.py:15)
+ *   tours_out (num_maps, n+1) int64: tour from node 0 back to node 0
+ *   maps_per_instance  heat map k belongs to instance k / maps_per_instance (parallel_sampling)
+ *   workspace at least tsp2opt_greedy_workspace_bytes(...) bytes (holds A + A^T)
+ * Edges are taken in increasing order of -A_ij/|v_i-v_j| (double); exactly equal keys of different
+ * edges are ordered by flat index i*n+j (the reference's order for ties is numpy's unstable argsort:
+ * undefined).  n <= 4500.
+ */
+int tsp2opt_greedy_decode(const void* heat, const double* points, int64_t* tours_out,
+                          int64_t num_maps, int32_t n, int32_t maps_per_instance, int32_t heat_dtype,
+                          int32_t device, void* workspace, int64_t workspace_bytes, void* hip_stream);
+int64_t tsp2opt_greedy_workspace_bytes(int64_t num_maps, int32_t n, int32_t heat_dtype);
+
+/*
  * tsp2opt_sqrt_check -- numerics self-test used by the GPU test-suite: out[k] = sqrt(in[k])
  * computed with the exact device routine the delta evaluation uses (dtype as above).  Lets the
  * tests prove 0-ulp agreement with the host's correctly rounded sqrt (SURVEY.md hard part b).

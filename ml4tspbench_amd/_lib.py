@@ -33,6 +33,8 @@ SYMBOLS = (
     "tsp2opt_workspace_bytes",
     "tsp2opt_tour_lengths",
     "tsp2opt_evaluate",
+    "tsp2opt_greedy_decode",
+    "tsp2opt_greedy_workspace_bytes",
     "tsp2opt_sqrt_check",
     "tsp2opt_plan",
     "tsp2opt_profile_enable",
@@ -69,6 +71,10 @@ def lib() -> ctypes.CDLL:
     L.tsp2opt_tour_lengths.restype = ctypes.c_int
     L.tsp2opt_evaluate.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
     L.tsp2opt_evaluate.restype = ctypes.c_int
+    L.tsp2opt_greedy_decode.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp]
+    L.tsp2opt_greedy_decode.restype = ctypes.c_int
+    L.tsp2opt_greedy_workspace_bytes.argtypes = [i64, i32, i32]
+    L.tsp2opt_greedy_workspace_bytes.restype = i64
     L.tsp2opt_sqrt_check.argtypes = [vp, vp, i64, i32, i32, vp]
     L.tsp2opt_sqrt_check.restype = ctypes.c_int
     L.tsp2opt_plan.argtypes = [i32, i32, i32, ctypes.POINTER(i32)]

@@ -13,7 +13,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = os.path.join(HERE, "csrc", "tsp2opt.hip")
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("tsp2opt.hip", "greedy.hip")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("wave_reduce.hpp", "host_util.hpp")]
 HDR = os.path.join(ROOT, "include", "tsp2opt.h")
 LIB = os.path.join(HERE, "libtsp2opt_hip.so")
 
@@ -21,15 +22,15 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
     "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
-    "-I", os.path.join(ROOT, "include"),
+    "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"),
 ]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    newest = max(os.path.getmtime(SRC), os.path.getmtime(HDR), os.path.getmtime(__file__))
+    newest = max(os.path.getmtime(f) for f in SRCS + DEPS + [HDR, __file__])
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
         return LIB
-    cmd = [HIPCC, *FLAGS, "-o", LIB, SRC]
+    cmd = [HIPCC, *FLAGS, "-o", LIB, *SRCS]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

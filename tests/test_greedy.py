@@ -1,0 +1,86 @@
+"""Greedy edge-merge decoder (row f1): the CPU oracle against the goldens made by the reference's own
+tsp_greedy (CPU), and the HIP decoder against both (GPU)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+
+FILES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "greedy_*.npz")))
+# the sparse fixture needs zero-score edges to join fragments; all of those tie exactly and the
+# reference orders ties by numpy's unstable argsort: parity unpinned there (only validity is checked)
+TIED = {"greedy_n100_sparse_p2"}
+
+
+def _load(path):
+    z = np.load(path)
+    d = {k: z[k] for k in z.files}
+    d["name"] = os.path.basename(path)[:-4]
+    return d
+
+
+def _dense(g):
+    from oracle import greedy_oracle
+    if "heatmap" in g:
+        return g["heatmap"]
+    return greedy_oracle.densify(g["values"], g["edge_index"], g["points"].shape[0])
+
+
+@pytest.mark.parametrize("path", FILES, ids=lambda p: os.path.basename(p)[:-4])
+def test_greedy_oracle_matches_reference_golden(path):
+    from oracle import greedy_oracle
+    g = _load(path)
+    t = greedy_oracle.greedy(g["points"], _dense(g))
+    n = g["points"].shape[0]
+    assert all(sorted(r[:-1]) == list(range(n)) and r[0] == 0 and r[-1] == 0 for r in t)
+    if g["name"] not in TIED:
+        assert np.array_equal(t, g["tours"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FILES, ids=lambda p: os.path.basename(p)[:-4])
+def test_gpu_greedy_matches_reference_golden(path):
+    from ml4tspbench_amd import tsp_greedy
+    from oracle import greedy_oracle
+    g = _load(path)
+    p = g["tours"].shape[0]
+    if "heatmap" in g:
+        tours = tsp_greedy(g["heatmap"], g["points"], parallel_sampling=p, device="cuda", extra_kwarg=1)
+    else:
+        tours = tsp_greedy(g["values"].reshape(-1), g["points"], edge_index_np=g["edge_index"],
+                           sparse_graph=True, parallel_sampling=p)
+    assert isinstance(tours, list) and len(tours) == p and isinstance(tours[0], list)
+    got = np.array(tours)
+    assert np.array_equal(got, greedy_oracle.greedy(g["points"], _dense(g)))   # same tie rule as the oracle
+    if g["name"] not in TIED:
+        assert np.array_equal(got, g["tours"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,inst,mpi,dtype", [(7, 3, 2, np.float32), (33, 5, 3, np.float64),
+                                             (100, 16, 4, np.float32), (257, 3, 2, np.float32),
+                                             (1000, 2, 1, np.float32)])
+def test_gpu_greedy_matches_oracle_random(n, inst, mpi, dtype):
+    from ml4tspbench_amd import greedy_decode_device, two_opt_device, evaluate_tours
+    from oracle import greedy_oracle
+    rng = np.random.default_rng(90 + n)
+    pts = rng.random((inst, n, 2))
+    heat = rng.random((inst * mpi, n, n)).astype(dtype)
+    dev = torch.device("cuda", 0)
+    d_pts = torch.from_numpy(pts).to(dev)
+    tours = greedy_decode_device(torch.from_numpy(heat).to(dev), d_pts, maps_per_instance=mpi)
+    torch.cuda.synchronize()
+    got = tours.cpu().numpy()
+    for k in range(inst * mpi):
+        ref = greedy_oracle.greedy(pts[k // mpi], heat[k])
+        assert np.array_equal(got[k], ref[0]), k
+    # the decoded tours feed the 2-opt kernel directly, all on the device
+    res = two_opt_device(d_pts, tours, tours_per_instance=mpi)
+    ev = evaluate_tours(d_pts, res.tours, tours_per_instance=mpi)
+    torch.cuda.synchronize()
+    assert ((ev.valid.cpu().numpy() & 7) == 7).all()
+    l0 = evaluate_tours(d_pts, tours, tours_per_instance=mpi).lengths
+    assert (ev.lengths <= l0 + 1e-9).all()
