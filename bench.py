@@ -176,6 +176,18 @@ def main():
     status = res.status.cpu().numpy()
     assert (status & 15).max(initial=0) == 0, "input rejected"
 
+    gap = None
+    if args.dtype == "f32" and rank == 0:
+        # north_star: "the fp32 path must give tour lengths within 1e-6 relative, with the optimality
+        # gap reported": the same start tours solved in fp64 (untimed), both lengths summed in double
+        r64 = amd.two_opt_device(d_pts.double(), d_tours, tours_per_instance=tpi, group_size=group,
+                                 max_iterations=args.max_iterations, want_lengths=True)
+        l32 = amd.evaluate_tours(d_pts.double(), res.tours, tours_per_instance=tpi).lengths
+        rel = (l32 - r64.lengths) / r64.lengths
+        gap = {"mean_rel_length_gap_fp32_vs_fp64": float(rel.mean().item()),
+               "max_abs_rel_length_gap": float(rel.abs().max().item()),
+               "identical_tours_fraction": float((res.tours == r64.tours).all(dim=1).double().mean().item())}
+
     out = None
     if rank == 0:
         main_ms = float(np.mean([k[0] for k in kern_ms])) if kern_ms else None
@@ -211,6 +223,8 @@ def main():
             "mean_iterations": it_sum / tours_total, "max_iterations_seen": it_max,
             "roofline": roof,
         }
+        if gap is not None:
+            out["fp32_vs_fp64"] = gap
         if not args.no_cpu:
             cb, ref_out, ref_it = cpu_baseline(args.config, pts, tours, tpi, group, args.max_iterations)
             k = len(ref_out)

@@ -57,17 +57,20 @@ constexpr int kMaxWaves = 16;         // 1024 threads
 constexpr int kModeIndep = 0;         // run from iteration 0 until the tour's own stop test
 constexpr int kModeForced = 1;        // continue to the group's iteration count (coupled mode)
 constexpr unsigned kNoMove = 0u;      // packed (i<<16|j) == 0 <=> flat argmin index 0 <=> no move
+constexpr unsigned kFullSweep = 0xffffffffu;   // "last move" value that asks for a full filter sweep
 
 struct Geo {                          // launch geometry of the filter sweep (host: make_plan)
     int n;                            // nodes
     int nt;                           // threads per workgroup
     int qclass;                       // 0: exact-only kernel; else sub-array stride Q
-    int GP;                           // lane groups; a lane owns diagonal groups gp and gp + GP
+    int GP;                           // lane groups; group gp owns cyclic diagonals 2+8gp .. 9+8gp
     int G;                            // = 2 * GP groups of 4 diagonals (cyclic diagonals 2..4G+1)
     int NS;                           // row segments
-    int MS;                           // macro steps (4 rows) per segment
+    int MS;                           // macro steps (4 rows) per segment, even: MS/2 tiles of 8 rows
     int xlds;                         // exact coordinates cached in LDS
-    int W;                            // window positions actually read (multiple of 4, <= 4*Q)
+    int W;                            // window entries kept consistent (multiple of 8, <= 8*Q)
+    int inc;                          // tile-minimum cache + incremental sweeps
+    int lcap;                         // capacity of the changed-tile list
     float eps2;                       // 2*eps of the filter, in scaled units
 };
 
@@ -105,7 +108,7 @@ struct Ctl {                          // LDS control block (first bytes of dynam
     float wmin[kMaxWaves];
     int pAmb[kMaxWaves];
     unsigned cand[kMaxCand];
-    unsigned ncand;
+    unsigned nlist;                   // changed tiles queued for this iteration
     int ambiguous;
     int tour_id;
     int flags;
@@ -155,16 +158,18 @@ template <typename T>
 struct View {
     Ctl* ctl;
     uint16_t* tour;        // n+1 positions
-    // filter copy, 4*Q entries each; slot(w) = (w&3)*Q + (w>>2), w = window (cyclic position) index;
-    // entry slot(w) = (value at w, value at w + 4*GP): the two streams of a lane in one 8-byte read
+    // filter copy, 8*Q entries each; slot(w) = (w&7)*Q + (w>>3), w = window (cyclic position) index;
+    // entry slot(w) = (value at w, value at w + 4): the two streams of a lane in one 8-byte read
     v2f* Xq;               // x
     v2f* Yq;               // y
     v2f* Eq;               // edge lengths e[w] = |P[w] P[w+1]|
+    float* Mc;             // filter minimum of every tile (8 rows x 8 diagonals), or null
+    uint16_t* list;        // ids of the tiles the last reversal touched
     const T* X;            // exact coordinates, node order (LDS copy or global)
 };
 
 template <int Q>
-__device__ __forceinline__ int slot(int w) { return (w & 3) * Q + (w >> 2); }
+__device__ __forceinline__ int slot(int w) { return (w & 7) * Q + (w >> 3); }
 
 // exact delta of position pair (i, j), i + 2 <= j <= n-1, in the reference's operation order
 template <typename T>
@@ -232,36 +237,59 @@ __device__ void block_best(Ctl* ctl, int tid, int nt, double& e, unsigned& idx)
 // ------------------------------------------------------------------------------------------
 // filter sweep
 // ------------------------------------------------------------------------------------------
-template <int Q>
+// Window geometry of one lane group gp: stream A walks diagonals 2+8gp .. 5+8gp, stream B the next
+// four, so the B operand of a column is the A operand 4 positions later = the .y half of the same
+// LDS entry.  Rows advance 4 per macro step; two macro steps (row parities PAR = 0, 1 of an 8-row
+// block rq) make one TILE of 8 rows x 8 diagonals = 64 pairs, the unit of the minimum cache.
+//
+// load_block<PAR>(b): per stream C[u] = P[8b + 4 PAR + 2 + u], E[u] = e[8b + 4 PAR + 1 + u]
+template <int Q, int PAR>
 __device__ __forceinline__ void load_block(const v2f* Xq, const v2f* Yq, const v2f* Eq, int b,
                                            v2f (&CX)[4], v2f (&CY)[4], v2f (&E)[4])
 {
-    // per stream: C[u] = P[4b+2+u], E[u] = e[4b+1+u]
-    CX[0] = Xq[2 * Q + b]; CX[1] = Xq[3 * Q + b]; CX[2] = Xq[b + 1]; CX[3] = Xq[Q + b + 1];
-    CY[0] = Yq[2 * Q + b]; CY[1] = Yq[3 * Q + b]; CY[2] = Yq[b + 1]; CY[3] = Yq[Q + b + 1];
-    E[0] = Eq[Q + b]; E[1] = Eq[2 * Q + b]; E[2] = Eq[3 * Q + b]; E[3] = Eq[b + 1];
+    if constexpr (PAR == 0) {
+        CX[0] = Xq[2 * Q + b]; CX[1] = Xq[3 * Q + b]; CX[2] = Xq[4 * Q + b]; CX[3] = Xq[5 * Q + b];
+        CY[0] = Yq[2 * Q + b]; CY[1] = Yq[3 * Q + b]; CY[2] = Yq[4 * Q + b]; CY[3] = Yq[5 * Q + b];
+        E[0] = Eq[Q + b]; E[1] = Eq[2 * Q + b]; E[2] = Eq[3 * Q + b]; E[3] = Eq[4 * Q + b];
+    } else {
+        CX[0] = Xq[6 * Q + b]; CX[1] = Xq[7 * Q + b]; CX[2] = Xq[b + 1]; CX[3] = Xq[Q + b + 1];
+        CY[0] = Yq[6 * Q + b]; CY[1] = Yq[7 * Q + b]; CY[2] = Yq[b + 1]; CY[3] = Yq[Q + b + 1];
+        E[0] = Eq[5 * Q + b]; E[1] = Eq[6 * Q + b]; E[2] = Eq[7 * Q + b]; E[3] = Eq[b + 1];
+    }
 }
 
-// One macro step: rows r0..r0+3 (r0 = 4*rowIdx) x the lane's 2 x 4 diagonals, 32 pairs.
-// Per stream:  Cold[u] = P[c0+u], Cnew[u] = P[c0+4+u], Eold[u] = e[c0-1+u], Enew[u] = e[c0+3+u],
-//   Dc[q] = D(r0, c0+q) on entry and D(r0+4, c0+4+q) on exit, c0 = r0 + 2 + 4*g.
-template <int Q>
+// One macro step: rows r0..r0+3, r0 = 8*rq + 4*PAR, x the lane's 2 x 4 diagonals, 32 pairs.
+// cb = rq + gp.  Per stream, with c0 = r0 + 2 + 8*gp:
+//   Cold[u] = P[c0+u], Cnew[u] = P[c0+4+u], Eold[u] = e[c0-1+u], Enew[u] = e[c0+3+u],
+//   Dc[q] = D(r0, c0+q) on entry and D(r0+4, c0+4+q) on exit.
+template <int Q, int PAR>
 __device__ __forceinline__ float macro_step(const v2f* Xq, const v2f* Yq, const v2f* Eq,
-                                            int rowIdx, int colIdx,
+                                            int rq, int cb,
                                             const v2f (&CXo)[4], const v2f (&CYo)[4], v2f (&CXn)[4],
                                             v2f (&CYn)[4], const v2f (&Eo)[4], v2f (&En)[4],
                                             v2f (&Dc)[4])
 {
-    load_block<Q>(Xq, Yq, Eq, colIdx, CXn, CYn, En);
+    load_block<Q, 1 - PAR>(Xq, Yq, Eq, cb + PAR, CXn, CYn, En);
     float rx[4], ry[4], er[4];
-    rx[0] = Xq[Q + rowIdx].x;     ry[0] = Yq[Q + rowIdx].x;         // P[r0+1]
-    rx[1] = Xq[2 * Q + rowIdx].x; ry[1] = Yq[2 * Q + rowIdx].x;     // P[r0+2]
-    rx[2] = Xq[3 * Q + rowIdx].x; ry[2] = Yq[3 * Q + rowIdx].x;     // P[r0+3]
-    rx[3] = Xq[rowIdx + 1].x;     ry[3] = Yq[rowIdx + 1].x;         // P[r0+4]
-    er[0] = Eq[rowIdx].x;                                           // e[r0]
-    er[1] = Eq[Q + rowIdx].x;
-    er[2] = Eq[2 * Q + rowIdx].x;
-    er[3] = Eq[3 * Q + rowIdx].x;
+    if constexpr (PAR == 0) {
+        rx[0] = Xq[Q + rq].x;     ry[0] = Yq[Q + rq].x;             // P[r0+1]
+        rx[1] = Xq[2 * Q + rq].x; ry[1] = Yq[2 * Q + rq].x;
+        rx[2] = Xq[3 * Q + rq].x; ry[2] = Yq[3 * Q + rq].x;
+        rx[3] = Xq[4 * Q + rq].x; ry[3] = Yq[4 * Q + rq].x;         // P[r0+4]
+        er[0] = Eq[rq].x;                                           // e[r0]
+        er[1] = Eq[Q + rq].x;
+        er[2] = Eq[2 * Q + rq].x;
+        er[3] = Eq[3 * Q + rq].x;
+    } else {
+        rx[0] = Xq[5 * Q + rq].x; ry[0] = Yq[5 * Q + rq].x;
+        rx[1] = Xq[6 * Q + rq].x; ry[1] = Yq[6 * Q + rq].x;
+        rx[2] = Xq[7 * Q + rq].x; ry[2] = Yq[7 * Q + rq].x;
+        rx[3] = Xq[rq + 1].x;     ry[3] = Yq[rq + 1].x;
+        er[0] = Eq[4 * Q + rq].x;
+        er[1] = Eq[5 * Q + rq].x;
+        er[2] = Eq[6 * Q + rq].x;
+        er[3] = Eq[7 * Q + rq].x;
+    }
     float mm = INFINITY;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -292,66 +320,161 @@ __device__ __forceinline__ void track(float mm, unsigned id, float& a1, float& a
     a1 = fminf(a1, mm);
 }
 
+// Tile ids: id = m2 * units + u, u = s * GP + gp the lane's unit (row segment s, lane group gp),
+// m2 = 8-row block inside the segment; the tile covers rows 8*(s*MS/2 + m2) .. +7.
+// Full sweep: every lane walks its own unit; the tile minima go to the cache when there is one.
 template <int Q>
-__device__ __forceinline__ void filter_sweep(const v2f* Xq, const v2f* Yq, const v2f* Eq,
+__device__ __forceinline__ void filter_sweep(const v2f* Xq, const v2f* Yq, const v2f* Eq, float* Mc,
                                              const Geo& g, int tid, float& a1, float& a2,
                                              unsigned& chunk)
 {
     a1 = INFINITY;
     a2 = INFINITY;
     chunk = 0;
-    const int units = g.GP * g.NS;
+    const int units = g.GP * g.NS, MS2 = g.MS >> 1;
     for (int u = tid; u < units; u += g.nt) {
         const int gp = u % g.GP, s = u / g.GP;
-        int rowIdx = s * g.MS;
-        int colIdx = rowIdx + gp + 1;
+        int rq = s * MS2;
+        int cb = rq + gp;
         v2f CX0[4], CY0[4], CX1[4], CY1[4], E0[4], E1[4], Dc[4];
-        load_block<Q>(Xq, Yq, Eq, colIdx - 1, CX0, CY0, E0);
-        const float ax = Xq[rowIdx].x, ay = Yq[rowIdx].x;   // P[r0]
+        load_block<Q, 0>(Xq, Yq, Eq, cb, CX0, CY0, E0);
+        const float ax = Xq[rq].x, ay = Yq[rq].x;           // P[r0]
 #pragma unroll
         for (int q = 0; q < 4; ++q) Dc[q] = dist32x2(ax, ay, CX0[q], CY0[q]);
-        unsigned id = (unsigned)u * (unsigned)g.MS;
-        int m = 0;
-        for (; m + 1 < g.MS; m += 2) {
-            float mm = macro_step<Q>(Xq, Yq, Eq, rowIdx, colIdx, CX0, CY0, CX1, CY1, E0, E1, Dc);
+        unsigned id = (unsigned)u;
+        for (int m2 = 0; m2 < MS2; ++m2) {
+            float mm = macro_step<Q, 0>(Xq, Yq, Eq, rq, cb, CX0, CY0, CX1, CY1, E0, E1, Dc);
+            mm = __builtin_fminf(mm, macro_step<Q, 1>(Xq, Yq, Eq, rq, cb, CX1, CY1, CX0, CY0, E1, E0, Dc));
+            if (Mc) Mc[id] = mm;
             track(mm, id, a1, a2, chunk);
-            mm = macro_step<Q>(Xq, Yq, Eq, rowIdx + 1, colIdx + 1, CX1, CY1, CX0, CY0, E1, E0, Dc);
-            track(mm, id + 1, a1, a2, chunk);
-            rowIdx += 2; colIdx += 2; id += 2;
-        }
-        if (m < g.MS) {
-            const float mm = macro_step<Q>(Xq, Yq, Eq, rowIdx, colIdx, CX0, CY0, CX1, CY1, E0, E1, Dc);
-            track(mm, id, a1, a2, chunk);
+            ++rq; ++cb; id += (unsigned)units;
         }
     }
 }
 
-// exact value of pair `pr` (0..31: stream, row, diagonal) of macro step `id`; returns packed index
+// filter minimum of one tile, from scratch (incremental sweeps)
+template <int Q>
+__device__ __forceinline__ float tile_min(const v2f* Xq, const v2f* Yq, const v2f* Eq, const Geo& g,
+                                          unsigned id)
+{
+    const int units = g.GP * g.NS, MS2 = g.MS >> 1;
+    const int u = (int)(id % (unsigned)units), m2 = (int)(id / (unsigned)units);
+    const int gp = u % g.GP, s = u / g.GP;
+    const int rq = s * MS2 + m2, cb = rq + gp;
+    v2f CX0[4], CY0[4], CX1[4], CY1[4], E0[4], E1[4], Dc[4];
+    load_block<Q, 0>(Xq, Yq, Eq, cb, CX0, CY0, E0);
+    const float ax = Xq[rq].x, ay = Yq[rq].x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Dc[q] = dist32x2(ax, ay, CX0[q], CY0[q]);
+    float mm = macro_step<Q, 0>(Xq, Yq, Eq, rq, cb, CX0, CY0, CX1, CY1, E0, E1, Dc);
+    return __builtin_fminf(mm, macro_step<Q, 1>(Xq, Yq, Eq, rq, cb, CX1, CY1, CX0, CY0, E1, E0, Dc));
+}
+
+// bits [a, b] of a 64-bit mask, clipped to [0, M-1]
+__device__ __forceinline__ unsigned long long bit_range(int a, int b, int M)
+{
+    a = a < 0 ? 0 : a;
+    b = b > M - 1 ? M - 1 : b;
+    if (a > b) return 0ull;
+    return (~0ull >> (63 - b)) & (~0ull << a);
+}
+
+// Filter sweep of one iteration.  `last` = the reversal applied since the previous sweep (packed
+// (i, j)) or kFullSweep.  With the tile cache, only tiles that read a changed window position
+// (coordinates i+1..j, edges i..j, any cyclic copy) are recomputed: every lane marks its own
+// touched tiles in closed form, the ids go to a list, the list is processed evenly by all lanes,
+// then every lane reduces its own cached tile minima exactly as the full sweep would.
+template <int Q, typename T>
+__device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, unsigned last,
+                                      float& a1, float& a2, unsigned& chunk)
+{
+    Ctl* ctl = v.ctl;
+    bool full = !g.inc || last == kFullSweep;
+    if (!full) {
+        const int units = g.GP * g.NS, MS2 = g.MS >> 1;
+        const int i = (int)(last >> 16), j = (int)(last & 0xffffu);
+        unsigned long long mask = 0ull;
+        if (tid < units) {
+            const int gp = tid % g.GP, rq0 = (tid / g.GP) * MS2;
+            for (int lo = i, hi = j; lo < g.W; lo += g.n, hi += g.n) {
+                mask |= bit_range((lo >> 3) - rq0, (hi >> 3) - rq0, MS2);                        // rows
+                mask |= bit_range(((lo - 9) >> 3) - gp - rq0, ((hi - 2) >> 3) - gp - rq0, MS2);  // columns
+            }
+        }
+        const int cnt = __popcll(mask);
+        if (cnt) {
+            unsigned pos = atomicAdd(&ctl->nlist, (unsigned)cnt);
+            while (mask) {
+                const int m2 = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                if (pos < (unsigned)g.lcap) v.list[pos] = (uint16_t)(m2 * units + tid);
+                ++pos;
+            }
+        }
+        __syncthreads();
+        const unsigned nl = ctl->nlist;
+        if (nl > (unsigned)g.lcap) {
+            full = true;                                    // most of the tour moved: plain sweep
+        } else {
+            __builtin_amdgcn_s_setprio(0);
+            for (unsigned t = (unsigned)tid; t < nl; t += (unsigned)g.nt) {
+                const unsigned id = v.list[t];
+                v.Mc[id] = tile_min<Q>(v.Xq, v.Yq, v.Eq, g, id);
+            }
+            __builtin_amdgcn_s_setprio(3);
+        }
+        __syncthreads();
+        if (tid == 0) ctl->nlist = 0;
+        if (!full) {
+            a1 = INFINITY;
+            a2 = INFINITY;
+            chunk = 0;
+            if (tid < units) {
+                unsigned id = (unsigned)tid;
+                for (int m2 = 0; m2 < MS2; ++m2) {
+                    track(v.Mc[id], id, a1, a2, chunk);
+                    id += (unsigned)units;
+                }
+            }
+            return;
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    filter_sweep<Q>(v.Xq, v.Yq, v.Eq, g.inc ? v.Mc : nullptr, g, tid, a1, a2, chunk);
+    __builtin_amdgcn_s_setprio(3);
+}
+
+// window positions (row, column) of pair `pr` (0..63: row 0..7, diagonal 0..7) of tile `id`
+__device__ __forceinline__ void tile_pair(const Geo& g, unsigned id, int pr, int& rw, int& cw)
+{
+    const int units = g.GP * g.NS, MS2 = g.MS >> 1;
+    const int u = (int)(id % (unsigned)units), m2 = (int)(id / (unsigned)units);
+    const int gp = u % g.GP, s = u / g.GP;
+    rw = 8 * (s * MS2 + m2) + (pr >> 3);
+    cw = rw + 2 + 8 * gp + (pr & 7);
+}
+
+// exact value of pair `pr` of tile `id`; returns packed index
 template <typename T>
 __device__ __forceinline__ void eval_chunk_pair(const View<T>& v, const Geo& g, unsigned id, int pr,
                                                 double& e, unsigned& idx)
 {
-    const int u = (int)(id / (unsigned)g.MS), m = (int)(id % (unsigned)g.MS);
-    const int gi = u % g.GP + (pr >> 4) * g.GP, s = u / g.GP;
-    const int r0 = 4 * (s * g.MS + m);
-    const int c0 = r0 + 2 + 4 * gi;
-    const int a = (pr >> 2) & 3, q = pr & 3;
-    const int r = (r0 + a) % g.n, c = (c0 + a + q) % g.n;
+    int rw, cw;
+    tile_pair(g, id, pr, rw, cw);
+    const int r = rw % g.n, c = cw % g.n;
     const int i = r < c ? r : c, j = r < c ? c : r;
     e = exact_delta(v, i, j);
     idx = ((unsigned)i << 16) | (unsigned)j;
 }
 
-// fp32 (filter) value of pair `pr` of macro step `id`, recomputed from the LDS window exactly as the
+// fp32 (filter) value of pair `pr` of tile `id`, recomputed from the LDS window exactly as the
 // sweep computes it, with the pair's packed index
 template <int Q, typename T>
 __device__ __forceinline__ void filter_chunk_pair(const View<T>& v, const Geo& g, unsigned id, int pr,
                                                   float& d, unsigned& idx)
 {
-    const int u = (int)(id / (unsigned)g.MS), m = (int)(id % (unsigned)g.MS);
-    const int gi = u % g.GP + (pr >> 4) * g.GP, s = u / g.GP;
-    const int a = (pr >> 2) & 3, q = pr & 3;
-    const int rw = 4 * (s * g.MS + m) + a, cw = rw + 2 + 4 * gi + q;    // window positions
+    int rw, cw;
+    tile_pair(g, id, pr, rw, cw);
     const int sr = slot<Q>(rw), sr1 = slot<Q>(rw + 1), sc = slot<Q>(cw), sc1 = slot<Q>(cw + 1);
     const float d0 = dist32(v.Xq[sr].x, v.Yq[sr].x, v.Xq[sc].x, v.Yq[sc].x);
     const float d1 = dist32(v.Xq[sr1].x, v.Yq[sr1].x, v.Xq[sc1].x, v.Yq[sc1].x);
@@ -366,8 +489,8 @@ __device__ __forceinline__ void filter_chunk_pair(const View<T>& v, const Geo& g
 // `need_exact_sign`: the caller needs the exact sign of a non-improving minimum (coupled-mode
 // continuation); otherwise a minimum proven >= -1e-6 by the filter alone ends the search.
 template <typename T, int Q>
-__device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exact_sign, double& e,
-                          unsigned& idx, Prof& pf)
+__device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exact_sign, unsigned last,
+                          double& e, unsigned& idx, Prof& pf)
 {
     Ctl* ctl = v.ctl;
     unsigned long long t0 = 0;
@@ -379,11 +502,10 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
     } else {
         float a1, a2;
         unsigned chunk;
-        __builtin_amdgcn_s_setprio(0);
-        filter_sweep<Q>(v.Xq, v.Yq, v.Eq, g, tid, a1, a2, chunk);
-        // everything between two sweeps is a latency chain that idles most of the workgroup: run it
-        // at high issue priority so the other workgroups' sweeps on this SIMD do not stretch it
-        __builtin_amdgcn_s_setprio(3);
+        // everything outside the sweep arithmetic is a latency chain that idles most of the
+        // workgroup: it runs at high issue priority (set inside sweep()) so that the other
+        // workgroups' sweeps on this SIMD do not stretch it
+        sweep<Q>(v, g, tid, last, a1, a2, chunk);
         if (pf.on) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
         const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
         const float wm = wave_min(a1);
@@ -412,23 +534,25 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
                 const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)cm) - 1);
                 cm &= cm - 1;
                 const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)chunk, src);
-                if (lane < 32) {
-                    float d;
-                    unsigned di;
-                    filter_chunk_pair<Q>(v, g, id, lane, d, di);
-                    if (d <= thr) {
-                        multi = multi || (fidx != 0xffffffffu && fidx != di);
-                        if (d < fd || (d == fd && di < fidx)) { fd = d; fidx = di; }
-                    }
+                float d;
+                unsigned di;
+                filter_chunk_pair<Q>(v, g, id, lane, d, di);
+                if (d <= thr) {
+                    multi = multi || (fidx != 0xffffffffu && fidx != di);
+                    if (d < fd || (d == fd && di < fidx)) { fd = d; fidx = di; }
                 }
             }
-            if (tid == 32) {    // the pair (0, n-1): cyclically adjacent, not on any walked diagonal
+            if (tid == 0) {     // the pair (0, n-1): cyclically adjacent, not on any walked diagonal
                 const int n = g.n;
                 const int s0 = slot<Q>(0), s1 = slot<Q>(1), sn1 = slot<Q>(n - 1), sn = slot<Q>(n);
                 const float d0 = dist32(v.Xq[s0].x, v.Yq[s0].x, v.Xq[sn1].x, v.Yq[sn1].x);
                 const float d1 = dist32(v.Xq[s1].x, v.Yq[s1].x, v.Xq[sn].x, v.Yq[sn].x);
                 const float d = ((d0 + d1) - v.Eq[sn1].x) - v.Eq[s0].x;
-                if (d <= thr) { fd = d; fidx = (unsigned)(n - 1); }
+                const unsigned di = (unsigned)(n - 1);
+                if (d <= thr) {
+                    multi = multi || (fidx != 0xffffffffu && fidx != di);
+                    if (d < fd || (d == fd && di < fidx)) { fd = d; fidx = di; }
+                }
             }
         }
         double wd = (double)fd;
@@ -481,14 +605,12 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
                 const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)cm) - 1);
                 cm &= cm - 1;
                 const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)chunk, src);
-                if (lane < 32) {
-                    double d;
-                    unsigned di;
-                    eval_chunk_pair(v, g, id, lane, d, di);
-                    if (better(d, di, e, idx)) { e = d; idx = di; }
-                }
+                double d;
+                unsigned di;
+                eval_chunk_pair(v, g, id, lane, d, di);
+                if (better(d, di, e, idx)) { e = d; idx = di; }
             }
-            if (tid == 32) {
+            if (tid == 0) {
                 const double d = exact_delta(v, 0, g.n - 1);
                 if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
             }
@@ -513,16 +635,18 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
 }
 
 // write the filter copy of position p: every window index w = p (mod n) is the A value of entry
-// slot(w) and the B value of entry slot(w - 4*GP)
+// slot(w) and the B value of entry slot(w - 4)
 template <int Q, typename T>
 __device__ __forceinline__ void put_xy(const View<T>& v, const Geo& g, int p, float x, float y)
 {
-    for (int w = p; w < g.W; w += g.n) {
-        const int s = slot<Q>(w);
-        v.Xq[s].x = x;
-        v.Yq[s].x = y;
-        if (w >= 4 * g.GP) {
-            const int sb = s - g.GP;        // slot(w - 4*GP): same sub-array, GP entries earlier
+    for (int w = p; w < g.W + 4; w += g.n) {
+        if (w < g.W) {
+            const int s = slot<Q>(w);
+            v.Xq[s].x = x;
+            v.Yq[s].x = y;
+        }
+        if (w >= 4) {
+            const int sb = slot<Q>(w - 4);
             v.Xq[sb].y = x;
             v.Yq[sb].y = y;
         }
@@ -532,10 +656,9 @@ __device__ __forceinline__ void put_xy(const View<T>& v, const Geo& g, int p, fl
 template <int Q, typename T>
 __device__ __forceinline__ void put_e(const View<T>& v, const Geo& g, int p, float e)
 {
-    for (int w = p; w < g.W; w += g.n) {
-        const int s = slot<Q>(w);
-        v.Eq[s].x = e;
-        if (w >= 4 * g.GP) v.Eq[s - g.GP].y = e;
+    for (int w = p; w < g.W + 4; w += g.n) {
+        if (w < g.W) v.Eq[slot<Q>(w)].x = e;
+        if (w >= 4) v.Eq[slot<Q>(w - 4)].y = e;
     }
 }
 
@@ -592,16 +715,25 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
     v.tour = reinterpret_cast<uint16_t*>(smem + off);
     off += align16(sizeof(uint16_t) * (size_t)(n + 1));
     v.Xq = reinterpret_cast<v2f*>(smem + off);
-    off += sizeof(v2f) * 4 * (size_t)Q;
+    off += sizeof(v2f) * 8 * (size_t)Q;
     v.Yq = reinterpret_cast<v2f*>(smem + off);
-    off += sizeof(v2f) * 4 * (size_t)Q;
+    off += sizeof(v2f) * 8 * (size_t)Q;
     v.Eq = reinterpret_cast<v2f*>(smem + off);
-    off += sizeof(v2f) * 4 * (size_t)Q;
+    off += sizeof(v2f) * 8 * (size_t)Q;
+    v.Mc = nullptr;
+    v.list = nullptr;
+    if (g.inc) {
+        const size_t tiles = (size_t)g.GP * g.NS * (g.MS >> 1);
+        v.Mc = reinterpret_cast<float*>(smem + off);
+        off += align16(sizeof(float) * tiles);
+        v.list = reinterpret_cast<uint16_t*>(smem + off);
+        off += align16(sizeof(uint16_t) * (size_t)g.lcap);
+    }
     T* xl = reinterpret_cast<T*>(smem + off);
     Ctl* ctl = v.ctl;
     for (;;) {
         __syncthreads();
-        if (tid == 0) ctl->tour_id = (int)atomicAdd(p.queue, 1u);
+        if (tid == 0) { ctl->tour_id = (int)atomicAdd(p.queue, 1u); ctl->nlist = 0; }
         __syncthreads();
         const int64_t tk = ctl->tour_id;
         if (tk >= p.num_tours) break;          // uniform exit: every wave leaves here
@@ -681,16 +813,16 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
         }
         if constexpr (Q != 0) {
             const double cx = ctl->cx, cy = ctl->cy, sc = ctl->sc;
-            for (int w = tid; w < 4 * Q; w += nt) {
-                const int na = v.tour[w % n], nb = v.tour[(w + 4 * g.GP) % n];
+            for (int w = tid; w < 8 * Q; w += nt) {
+                const int na = v.tour[w % n], nb = v.tour[(w + 4) % n];
                 const double xa = (double)v.X[2 * na], ya = (double)v.X[2 * na + 1];
                 const double xb = (double)v.X[2 * nb], yb = (double)v.X[2 * nb + 1];
                 v.Xq[slot<Q>(w)] = (v2f){(float)((xa - cx) * sc), (float)((xb - cx) * sc)};
                 v.Yq[slot<Q>(w)] = (v2f){(float)((ya - cy) * sc), (float)((yb - cy) * sc)};
             }
             __syncthreads();
-            for (int w = tid; w < 4 * Q; w += nt) {
-                const int s0 = slot<Q>(w), s1 = slot<Q>(w + 1 < 4 * Q ? w + 1 : w);
+            for (int w = tid; w < 8 * Q; w += nt) {
+                const int s0 = slot<Q>(w), s1 = slot<Q>(w + 1 < 8 * Q ? w + 1 : w);
                 const v2f x0 = v.Xq[s0], y0 = v.Yq[s0], x1 = v.Xq[s1], y1 = v.Yq[s1];
                 v.Eq[s0] = (v2f){dist32(x0.x, y0.x, x1.x, y1.x), dist32(x0.y, y0.y, x1.y, y1.y)};
             }
@@ -709,7 +841,7 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
                 for (int k = 0; k < p.dbg_sweeps; ++k) {
                     float a1, a2;
                     unsigned chunk;
-                    filter_sweep<Q>(v.Xq, v.Yq, v.Eq, g, tid, a1, a2, chunk);
+                    filter_sweep<Q>(v.Xq, v.Yq, v.Eq, v.Mc, g, tid, a1, a2, chunk);
                     acc += a1 + a2 + (float)chunk;
                     asm volatile("" ::: "memory");
                 }
@@ -728,10 +860,11 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
         const bool forced = p.mode == kModeForced;
         bool have_prev = false, prev_active = false, active_at_target = false;
         unsigned prev_idx = kNoMove;
+        unsigned last = kFullSweep;             // reversal applied since the previous sweep
         for (;;) {
             const bool check_only = forced && it >= target;
             if (check_only && target >= p.max_iter) break;
-            find_best<T, Q>(v, g, tid, forced, e, idx, pf);
+            find_best<T, Q>(v, g, tid, forced, last, e, idx, pf);
             ++sweeps;
             const bool active = e < -1.0e-6;
             bool stop_after = false;
@@ -752,6 +885,7 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
             unsigned long long ta = 0;
             if (pf.on) ta = clock64();
             apply_move<T, Q>(v, g, tid, idx);
+            last = idx;
             if (pf.on) pf.apply += clock64() - ta;
             if (stop_after) break;
             ++it;
@@ -1511,7 +1645,7 @@ struct Plan {
 };
 
 constexpr size_t kLdsMax = 160 * 1024;
-const int kQClasses[] = {64, 128, 256, 512, 1024, 2048};
+const int kQClasses[] = {16, 32, 64, 128, 256, 512};
 
 Plan make_plan(int n, int dtype)
 {
@@ -1526,31 +1660,45 @@ Plan make_plan(int n, int dtype)
     int nt = n <= 160 ? 64 : n <= 320 ? 128 : n <= 640 ? 256 : n <= 1280 ? 512 : 1024;
     g.nt = nt;
     g.qclass = 0;
+    size_t cache = 0;
     {
         const int dn = n / 2 - 1;                       // cyclic diagonals 2..n/2
-        const int GP = ((dn + 3) / 4 + 1) / 2;          // lane groups, two diagonal groups each
+        const int GP = (dn + 7) / 8;                    // lane groups of 8 adjacent diagonals
         const int G = 2 * GP;
-        // every walked diagonal d = 2..4G+1 must be a valid pair distance: d <= n-2
-        if (GP >= 1 && 4 * G + 1 <= n - 2) {
+        // every walked diagonal d = 2..8GP+1 must be a valid pair distance: d <= n-2
+        if (GP >= 1 && 8 * GP + 1 <= n - 2) {
             const int R = (n + 3) / 4;                  // macro-step rows needed
             int NS = nt / GP;
             if (NS < 1) NS = 1;
-            if (NS > R) NS = R;
-            const int MS = (R + NS - 1) / NS;
+            if (NS > (R + 1) / 2) NS = (R + 1) / 2;
+            int MS = (R + NS - 1) / NS;
+            MS += MS & 1;                               // tiles are two macro steps
+            NS = (R + MS - 1) / MS;                     // drop segments that would be pure padding
             const int rows = 4 * NS * MS;
-            const int W = rows + 4 * G + 8;
-            const int q = (W + 3) / 4 + 1;
+            const int W = rows + 8 * GP + 8;            // multiple of 8
+            const int q = W / 8 + 1;
             for (int qc : kQClasses) {
-                if (qc >= q && base + (size_t)qc * 96 <= kLdsMax) {
+                if (qc >= q && base + (size_t)qc * 192 <= kLdsMax) {
                     g.qclass = qc; g.GP = GP; g.G = G; g.NS = NS; g.MS = MS;
-                    g.W = (W + 3) & ~3;
+                    g.W = W;
                     pl.S = 4 * MS; pl.W = W;
                     break;
                 }
             }
+            if (g.qclass) {
+                // minimum cache (4 B per tile) + changed-tile list (2 B per entry, half the tiles)
+                const size_t tiles = (size_t)GP * NS * (MS / 2);
+                const size_t need = align16(4 * tiles) + align16(2 * (tiles / 2 + 1));
+                if (tiles <= 65535 && MS / 2 <= 64 && GP * NS <= nt &&
+                    base + (size_t)g.qclass * 192 + need <= kLdsMax) {
+                    g.inc = 1;
+                    g.lcap = (int)(tiles / 2 + 1);
+                    cache = need;
+                }
+            }
         }
     }
-    pl.lds = base + (size_t)g.qclass * 96;
+    pl.lds = base + (size_t)g.qclass * 192 + cache;
     // cache the exact coordinates in LDS when that still leaves >= 4 workgroups per CU (or fits at all
     // for single-workgroup-per-CU sizes)
     g.xlds = 0;
@@ -1586,12 +1734,12 @@ int dispatch_main(const Params& p, const Plan& pl, int device, hipStream_t strea
 {
     switch (pl.g.qclass) {
     case 0: return launch_main<T, 0>(p, pl, device, stream, bpc);
+    case 16: return launch_main<T, 16>(p, pl, device, stream, bpc);
+    case 32: return launch_main<T, 32>(p, pl, device, stream, bpc);
     case 64: return launch_main<T, 64>(p, pl, device, stream, bpc);
     case 128: return launch_main<T, 128>(p, pl, device, stream, bpc);
     case 256: return launch_main<T, 256>(p, pl, device, stream, bpc);
     case 512: return launch_main<T, 512>(p, pl, device, stream, bpc);
-    case 1024: return launch_main<T, 1024>(p, pl, device, stream, bpc);
-    case 2048: return launch_main<T, 2048>(p, pl, device, stream, bpc);
     }
     return fail(TSP2OPT_E_ARG, "internal: bad filter class");
 }

@@ -22,7 +22,9 @@ def pytest_configure(config):
 
 
 def golden_files():
-    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """2-opt fixtures (oracle/gen_golden.py); the greedy decoder's are greedy_*.npz (tests/test_greedy.py)."""
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
+                  if not os.path.basename(f).startswith("greedy_"))
 
 
 def load_golden(path):

@@ -65,6 +65,6 @@ def test_plan_is_consistent():
                 assert 4 * G + 1 <= n - 2            # every walked diagonal is a valid pair distance
                 assert 4 * G + 1 >= n // 2           # ... and all of them are covered
                 assert 4 * NS * MS >= n              # all rows are covered
-                assert 4 * NS * MS + 4 * G + 8 <= 4 * pl["filter_class"]   # window fits the LDS arrays
+                assert 4 * NS * MS + 4 * G + 8 <= 8 * pl["filter_class"]   # window fits the LDS arrays
     with pytest.raises(_lib.Tsp2optError):
         _lib.plan(0)

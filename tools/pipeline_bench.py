@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""tools/pipeline_bench.py -- decode -> 2-opt -> validate/select, all on one MI355X.
+
+The reference's test-time pipeline for one batch (models/modelzoo/gnn/tsp_gnn.py:190-221): greedy
+edge-merge decode of every heat map (CPU, one core), 2-opt on the decoded tours, validity check,
+cost of every tour, best of the P samples.  Here the three stages are three library calls on device
+tensors (tsp2opt_greedy_decode, tsp2opt_solve, tsp2opt_evaluate); this tool times each with HIP
+events on the current stream and checks a sample against the CPU oracles.
+
+Heat maps are synthetic (no checkpoints here): exp(-d_ij / tau) times per-sample multiplicative
+noise, i.e. a "nearest edges are hot" map that decodes to a reasonable but unoptimised tour, the
+kind of start 2-opt sees in the reference (BASELINE.json configs[0..3]).  --knn K zeroes everything
+outside each node's K nearest neighbours (configs[3]'s sparse k=50 heat map, densified as
+greedy_search.py:41-47 does).
+
+    python tools/pipeline_bench.py --config tsp100 [--steps 3] [--knn 0] [--check 2]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {            # N, instances, heat maps per instance  (BASELINE.json configs)
+    "tsp50": (50, 1280, 1),
+    "tsp100": (100, 10000, 1),
+    "tsp500": (500, 128, 16),
+    "tsp1000": (1000, 128, 1),
+}
+
+
+def make_heat(pts: torch.Tensor, per: int, knn: int, seed: int) -> torch.Tensor:
+    """(I,N,2) float64 -> (I*per, N, N) float32 heat maps, built in chunks on the device."""
+    inst, n, _ = pts.shape
+    g = torch.Generator(device=pts.device)
+    g.manual_seed(seed)
+    out = torch.empty((inst * per, n, n), dtype=torch.float32, device=pts.device)
+    tau = 0.35 / np.sqrt(n)
+    step = max(1, (1 << 26) // (n * n * per))
+    for a in range(0, inst, step):
+        p = pts[a:a + step]
+        d = torch.cdist(p, p)                                    # (c,N,N) float64
+        h = torch.exp(-d / tau).to(torch.float32)
+        if knn:
+            kth = d.topk(knn + 1, dim=-1, largest=False).values[..., -1:]
+            h = torch.where(d <= kth, h, torch.zeros_like(h))
+        h = h.repeat_interleave(per, dim=0)
+        noise = 0.6 + 0.8 * torch.rand(h.shape, generator=g, device=pts.device, dtype=torch.float32)
+        h = h * noise
+        h.diagonal(dim1=-2, dim2=-1).zero_()
+        out[a * per:(a + step) * per] = h
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="tsp100", choices=sorted(CONFIGS))
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--knn", type=int, default=0)
+    ap.add_argument("--check", type=int, default=2, help="instances checked against the CPU oracles")
+    ap.add_argument("--max-iterations", type=int, default=5000)
+    args = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("needs an MI355X")
+    dev = torch.device("cuda", 0)
+    import ml4tspbench_amd as amd
+
+    n, inst, per = CONFIGS[args.config]
+    rng = np.random.default_rng(1234)
+    pts_np = rng.random((inst, n, 2))
+    pts = torch.from_numpy(pts_np).to(dev)
+    heat = make_heat(pts, per, args.knn, 1234)
+    torch.cuda.synchronize()
+
+    def run():
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        tours = amd.greedy_decode_device(heat, pts, maps_per_instance=per)
+        ev[1].record()
+        res = amd.two_opt_device(pts, tours, tours_per_instance=per, group_size=1,
+                                 max_iterations=args.max_iterations, want_lengths=False)
+        ev[2].record()
+        sel = amd.evaluate_tours(pts, res.tours, tours_per_instance=per)
+        ev[3].record()
+        torch.cuda.synchronize()
+        return tours, res, sel, [ev[k].elapsed_time(ev[k + 1]) for k in range(3)]
+
+    run()
+    times = []
+    for _ in range(args.steps):
+        tours, res, sel, t = run()
+        times.append(t)
+    t = np.mean(np.array(times), axis=0)
+    start_len = amd.evaluate_tours(pts, tours, tours_per_instance=per)
+    valid = sel.valid.cpu().numpy()
+    pairs = (n - 1) * (n - 2) // 2
+    sweeps = int(res.sweeps.to(torch.int64).sum().item())
+    out = {
+        "config": args.config, "nodes": n, "instances": inst, "maps_per_instance": per, "knn": args.knn,
+        "ms": {"greedy_decode": float(t[0]), "two_opt": float(t[1]), "evaluate": float(t[2]),
+               "total": float(t.sum())},
+        "instances_per_s": inst / (float(t.sum()) * 1e-3),
+        "tours_per_s": inst * per / (float(t.sum()) * 1e-3),
+        "two_opt_pair_deltas_per_s": sweeps * pairs / (float(t[1]) * 1e-3),
+        "mean_2opt_iterations": float(res.iterations.double().mean().item()),
+        "all_valid": bool(((valid & 3) == 3).all()),
+        "mean_length_decoded": float(start_len.lengths.mean().item()),
+        "mean_length_after_2opt": float(sel.lengths.mean().item()),
+        "mean_length_best_of_p": float(sel.best_length.mean().item()),
+    }
+    if args.check:
+        from oracle import greedy_oracle, two_opt_oracle
+        c = min(args.check, inst)
+        h_np = heat[:c * per].cpu().numpy()
+        ok_g = ok_t = True
+        for k in range(c):
+            ref_t = greedy_oracle.greedy(pts_np[k], h_np[k * per:(k + 1) * per])
+            ok_g &= bool(np.array_equal(ref_t, tours[k * per:(k + 1) * per].cpu().numpy()))
+            ref_o, ref_it, _ = two_opt_oracle.solve(pts_np[k:k + 1], ref_t, tours_per_instance=per, group_size=1,
+                                                    max_iterations=args.max_iterations, threads=1)
+            ok_t &= bool(np.array_equal(ref_o, res.tours[k * per:(k + 1) * per].cpu().numpy()))
+        out["sample_matches_oracles"] = {"instances": c, "greedy": ok_g, "two_opt": ok_t}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
