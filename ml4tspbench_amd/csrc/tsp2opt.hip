@@ -320,8 +320,9 @@ __device__ __forceinline__ void track(float mm, unsigned id, float& a1, float& a
     a1 = fminf(a1, mm);
 }
 
-// Tile ids: id = m2 * units + u, u = s * GP + gp the lane's unit (row segment s, lane group gp),
-// m2 = 8-row block inside the segment; the tile covers rows 8*(s*MS/2 + m2) .. +7.
+// Tile ids: id = (rq << 8) | gp, rq = 8-row block of the whole window (segment s of unit
+// u = s * GP + gp covers rq = s*MS/2 .. (s+1)*MS/2 - 1), gp = lane group (< 256); the cached minimum
+// of the tile sits at Mc[rq * GP + gp].
 // Full sweep: every lane walks its own unit; the tile minima go to the cache when there is one.
 template <int Q>
 __device__ __forceinline__ void filter_sweep(const v2f* Xq, const v2f* Yq, const v2f* Eq, float* Mc,
@@ -341,26 +342,23 @@ __device__ __forceinline__ void filter_sweep(const v2f* Xq, const v2f* Yq, const
         const float ax = Xq[rq].x, ay = Yq[rq].x;           // P[r0]
 #pragma unroll
         for (int q = 0; q < 4; ++q) Dc[q] = dist32x2(ax, ay, CX0[q], CY0[q]);
-        unsigned id = (unsigned)u;
+        unsigned id = ((unsigned)rq << 8) | (unsigned)gp;
+        float* mc = Mc ? Mc + rq * g.GP + gp : nullptr;
         for (int m2 = 0; m2 < MS2; ++m2) {
             float mm = macro_step<Q, 0>(Xq, Yq, Eq, rq, cb, CX0, CY0, CX1, CY1, E0, E1, Dc);
             mm = __builtin_fminf(mm, macro_step<Q, 1>(Xq, Yq, Eq, rq, cb, CX1, CY1, CX0, CY0, E1, E0, Dc));
-            if (Mc) Mc[id] = mm;
+            if (mc) { *mc = mm; mc += g.GP; }
             track(mm, id, a1, a2, chunk);
-            ++rq; ++cb; id += (unsigned)units;
+            ++rq; ++cb; id += 256u;
         }
     }
 }
 
 // filter minimum of one tile, from scratch (incremental sweeps)
 template <int Q>
-__device__ __forceinline__ float tile_min(const v2f* Xq, const v2f* Yq, const v2f* Eq, const Geo& g,
-                                          unsigned id)
+__device__ __forceinline__ float tile_min(const v2f* Xq, const v2f* Yq, const v2f* Eq, int rq, int gp)
 {
-    const int units = g.GP * g.NS, MS2 = g.MS >> 1;
-    const int u = (int)(id % (unsigned)units), m2 = (int)(id / (unsigned)units);
-    const int gp = u % g.GP, s = u / g.GP;
-    const int rq = s * MS2 + m2, cb = rq + gp;
+    const int cb = rq + gp;
     v2f CX0[4], CY0[4], CX1[4], CY1[4], E0[4], E1[4], Dc[4];
     load_block<Q, 0>(Xq, Yq, Eq, cb, CX0, CY0, E0);
     const float ax = Xq[rq].x, ay = Yq[rq].x;
@@ -379,36 +377,49 @@ __device__ __forceinline__ unsigned long long bit_range(int a, int b, int M)
     return (~0ull >> (63 - b)) & (~0ull << a);
 }
 
+struct Unit {               // the lane's own unit, fixed for the whole kernel
+    int gp;                 // lane group, or -1 when the lane owns no unit
+    int rq0;                // first 8-row block of its row segment
+};
+
 // Filter sweep of one iteration.  `last` = the reversal applied since the previous sweep (packed
 // (i, j)) or kFullSweep.  With the tile cache, only tiles that read a changed window position
 // (coordinates i+1..j, edges i..j, any cyclic copy) are recomputed: every lane marks its own
-// touched tiles in closed form, the ids go to a list, the list is processed evenly by all lanes,
-// then every lane reduces its own cached tile minima exactly as the full sweep would.
+// touched tiles in closed form, the ids are compacted into a list (ballot per row block, one LDS
+// atomic per wave), the list is processed evenly by all lanes, then every lane reduces its own
+// cached tile minima exactly as the full sweep would.
 template <int Q, typename T>
-__device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, unsigned last,
-                                      float& a1, float& a2, unsigned& chunk)
+__device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, const Unit& un,
+                                      unsigned last, float& a1, float& a2, unsigned& chunk)
 {
     Ctl* ctl = v.ctl;
     bool full = !g.inc || last == kFullSweep;
     if (!full) {
-        const int units = g.GP * g.NS, MS2 = g.MS >> 1;
+        const int MS2 = g.MS >> 1;
         const int i = (int)(last >> 16), j = (int)(last & 0xffffu);
         unsigned long long mask = 0ull;
-        if (tid < units) {
-            const int gp = tid % g.GP, rq0 = (tid / g.GP) * MS2;
+        if (un.gp >= 0) {
             for (int lo = i, hi = j; lo < g.W; lo += g.n, hi += g.n) {
-                mask |= bit_range((lo >> 3) - rq0, (hi >> 3) - rq0, MS2);                        // rows
-                mask |= bit_range(((lo - 9) >> 3) - gp - rq0, ((hi - 2) >> 3) - gp - rq0, MS2);  // columns
+                mask |= bit_range((lo >> 3) - un.rq0, (hi >> 3) - un.rq0, MS2);                              // rows
+                mask |= bit_range(((lo - 9) >> 3) - un.gp - un.rq0, ((hi - 2) >> 3) - un.gp - un.rq0, MS2);  // columns
             }
         }
-        const int cnt = __popcll(mask);
-        if (cnt) {
-            unsigned pos = atomicAdd(&ctl->nlist, (unsigned)cnt);
-            while (mask) {
-                const int m2 = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                if (pos < (unsigned)g.lcap) v.list[pos] = (uint16_t)(m2 * units + tid);
-                ++pos;
+        // compaction: wave total -> one atomic -> per-lane positions by ballot rank
+        unsigned wtotal = 0;
+        for (int m2 = 0; m2 < MS2; ++m2) wtotal += (unsigned)__popcll(__ballot((mask >> m2) & 1ull));
+        unsigned base = 0;
+        if (wtotal) {
+            if ((tid & 63) == 0) base = atomicAdd(&ctl->nlist, wtotal);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            for (int m2 = 0; m2 < MS2; ++m2) {
+                const unsigned long long b = __ballot((mask >> m2) & 1ull);
+                if ((mask >> m2) & 1ull) {
+                    const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+                    if (pos < (unsigned)g.lcap)
+                        v.list[pos] = (uint16_t)(((unsigned)(un.rq0 + m2) << 8) | (unsigned)un.gp);
+                }
+                base += (unsigned)__popcll(b);
             }
         }
         __syncthreads();
@@ -419,7 +430,8 @@ __device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, u
             __builtin_amdgcn_s_setprio(0);
             for (unsigned t = (unsigned)tid; t < nl; t += (unsigned)g.nt) {
                 const unsigned id = v.list[t];
-                v.Mc[id] = tile_min<Q>(v.Xq, v.Yq, v.Eq, g, id);
+                const int rq = (int)(id >> 8), gp = (int)(id & 255u);
+                v.Mc[rq * g.GP + gp] = tile_min<Q>(v.Xq, v.Yq, v.Eq, rq, gp);
             }
             __builtin_amdgcn_s_setprio(3);
         }
@@ -429,11 +441,13 @@ __device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, u
             a1 = INFINITY;
             a2 = INFINITY;
             chunk = 0;
-            if (tid < units) {
-                unsigned id = (unsigned)tid;
+            if (un.gp >= 0) {
+                unsigned id = ((unsigned)un.rq0 << 8) | (unsigned)un.gp;
+                const float* mc = v.Mc + un.rq0 * g.GP + un.gp;
                 for (int m2 = 0; m2 < MS2; ++m2) {
-                    track(v.Mc[id], id, a1, a2, chunk);
-                    id += (unsigned)units;
+                    track(*mc, id, a1, a2, chunk);
+                    id += 256u;
+                    mc += g.GP;
                 }
             }
             return;
@@ -447,11 +461,8 @@ __device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, u
 // window positions (row, column) of pair `pr` (0..63: row 0..7, diagonal 0..7) of tile `id`
 __device__ __forceinline__ void tile_pair(const Geo& g, unsigned id, int pr, int& rw, int& cw)
 {
-    const int units = g.GP * g.NS, MS2 = g.MS >> 1;
-    const int u = (int)(id % (unsigned)units), m2 = (int)(id / (unsigned)units);
-    const int gp = u % g.GP, s = u / g.GP;
-    rw = 8 * (s * MS2 + m2) + (pr >> 3);
-    cw = rw + 2 + 8 * gp + (pr & 7);
+    rw = 8 * (int)(id >> 8) + (pr >> 3);
+    cw = rw + 2 + 8 * (int)(id & 255u) + (pr & 7);
 }
 
 // exact value of pair `pr` of tile `id`; returns packed index
@@ -489,8 +500,8 @@ __device__ __forceinline__ void filter_chunk_pair(const View<T>& v, const Geo& g
 // `need_exact_sign`: the caller needs the exact sign of a non-improving minimum (coupled-mode
 // continuation); otherwise a minimum proven >= -1e-6 by the filter alone ends the search.
 template <typename T, int Q>
-__device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exact_sign, unsigned last,
-                          double& e, unsigned& idx, Prof& pf)
+__device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& un, bool need_exact_sign,
+                          unsigned last, double& e, unsigned& idx, Prof& pf)
 {
     Ctl* ctl = v.ctl;
     unsigned long long t0 = 0;
@@ -505,7 +516,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
         // everything outside the sweep arithmetic is a latency chain that idles most of the
         // workgroup: it runs at high issue priority (set inside sweep()) so that the other
         // workgroups' sweeps on this SIMD do not stretch it
-        sweep<Q>(v, g, tid, last, a1, a2, chunk);
+        sweep<Q>(v, g, tid, un, last, a1, a2, chunk);
         if (pf.on) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
         const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
         const float wm = wave_min(a1);
@@ -731,6 +742,10 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
     }
     T* xl = reinterpret_cast<T*>(smem + off);
     Ctl* ctl = v.ctl;
+    Unit un{-1, 0};
+    if constexpr (Q != 0) {
+        if (tid < g.GP * g.NS) { un.gp = tid % g.GP; un.rq0 = (tid / g.GP) * (g.MS >> 1); }
+    }
     for (;;) {
         __syncthreads();
         if (tid == 0) { ctl->tour_id = (int)atomicAdd(p.queue, 1u); ctl->nlist = 0; }
@@ -864,7 +879,7 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
         for (;;) {
             const bool check_only = forced && it >= target;
             if (check_only && target >= p.max_iter) break;
-            find_best<T, Q>(v, g, tid, forced, last, e, idx, pf);
+            find_best<T, Q>(v, g, tid, un, forced, last, e, idx, pf);
             ++sweeps;
             const bool active = e < -1.0e-6;
             bool stop_after = false;
@@ -1689,7 +1704,7 @@ Plan make_plan(int n, int dtype)
                 // minimum cache (4 B per tile) + changed-tile list (2 B per entry, half the tiles)
                 const size_t tiles = (size_t)GP * NS * (MS / 2);
                 const size_t need = align16(4 * tiles) + align16(2 * (tiles / 2 + 1));
-                if (tiles <= 65535 && MS / 2 <= 64 && GP * NS <= nt &&
+                if ((size_t)NS * (MS / 2) <= 255 && GP <= 255 && MS / 2 <= 64 && GP * NS <= nt &&
                     base + (size_t)g.qclass * 192 + need <= kLdsMax) {
                     g.inc = 1;
                     g.lcap = (int)(tiles / 2 + 1);
