@@ -1701,7 +1701,8 @@ Plan make_plan(int n, int dtype)
                 }
             }
             if (g.qclass) {
-                // minimum cache (4 B per tile) + changed-tile list (2 B per entry, half the tiles)
+                // minimum cache (4 B per tile) + changed-tile list (2 B per entry, half the tiles: measured,
+                // beyond that a plain sweep is cheaper than recomputing tile by tile)
                 const size_t tiles = (size_t)GP * NS * (MS / 2);
                 const size_t need = align16(4 * tiles) + align16(2 * (tiles / 2 + 1));
                 if ((size_t)NS * (MS / 2) <= 255 && GP <= 255 && MS / 2 <= 64 && GP * NS <= nt &&

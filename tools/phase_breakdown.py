@@ -11,6 +11,9 @@ from ml4tspbench_amd import _lib, two_opt
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "tsp500"
 dt = np.float64 if (len(sys.argv) < 3 or sys.argv[2] == "f64") else np.float32
+if len(sys.argv) > 4:        # override the number of instances (e.g. one workgroup per CU: no SIMD sharing)
+    n_, i_, t_ = bench.CONFIGS[cfg]
+    bench.CONFIGS[cfg] = (n_, int(sys.argv[4]), t_)
 pts, tours, tpi = bench.make_batch(cfg, 1234, dt)
 CAP = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
 dev = torch.device("cuda", 0)
@@ -43,5 +46,5 @@ t0.record(); amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi); t1.reco
 L.tsp2opt_debug_sweep_only(0)
 n = pts.shape[1]; pairs = (n - 1) * (n - 2) // 2
 ms = t0.elapsed_time(t1)
-print(f"sweep-only: {K} sweeps x {len(tours)} tours in {ms:.2f} ms -> {K*len(tours)*pairs/ms/1e9:.1f} G useful pair-deltas/s "
+print(f"sweep-only: {K} sweeps x {len(tours)} tours in {ms:.2f} ms -> {K*len(tours)*pairs/ms/1e6:.1f} G useful pair-deltas/s "
       f"({ms*1e-3*2.4e9*1024/(K*len(tours)*pairs/64):.1f} SIMD-cycles@2.4GHz per 64 pairs)")
