@@ -151,6 +151,12 @@ int tsp2opt_sqrt_check(const void* in, void* out, int64_t count, int32_t dtype, 
  * out[3]=row segments, out[4]=diagonal groups, out[5]=macro steps, out[6]=resident workgroups/CU */
 int tsp2opt_plan(int32_t n, int32_t dtype, int32_t device, int32_t* out7);
 
+/* Diagnostic, no counterpart in the reference: phase timers of the greedy decoder's merge loop.
+ * enable = 1 zeroes and switches them on for `device`; enable = 0 switches them off and copies
+ * out8 = {scan cycles, merge cycles, rescan cycles, merges, rescans, loop cycles, 0, 0} summed over
+ * the heat maps decoded in between.  Synchronises the device. */
+int tsp2opt_debug_greedy_cycles(int32_t enable, int32_t device, uint64_t* out8);
+
 /*
  * Optional timing of the persistent kernel: after tsp2opt_profile_enable(1) every tsp2opt_solve
  * brackets its main kernel (and, in coupled mode, the continuation kernel) with HIP events on the

@@ -37,6 +37,7 @@ SYMBOLS = (
     "tsp2opt_greedy_workspace_bytes",
     "tsp2opt_sqrt_check",
     "tsp2opt_plan",
+    "tsp2opt_debug_greedy_cycles",
     "tsp2opt_profile_enable",
     "tsp2opt_profile_last_ms",
     "tsp2opt_debug_phase_cycles",

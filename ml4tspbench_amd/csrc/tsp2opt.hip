@@ -678,7 +678,7 @@ template <typename T, int Q>
 __device__ void apply_move(const View<T>& v, const Geo& g, int tid, unsigned idx)
 {
     const int i = (int)(idx >> 16), j = (int)(idx & 0xffffu);
-    const int n = g.n;
+
     const int L = j - i;
     const int h = L >> 1;
     for (int k = tid; k < h; k += g.nt) {
