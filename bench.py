@@ -55,31 +55,38 @@ def make_batch(name: str, seed: int, dtype):
 
 def cpu_baseline(name: str, pts: np.ndarray, tours: np.ndarray, tpi: int, group: int, cap: int):
     """The oracle (oracle/two_opt_oracle.c, a port of the reference algorithm) timed on this box's
-    host cores on a bounded sample of the same workload."""
+    host cores on a bounded sample of the same workload (about 20 s of CPU work): the first `want`
+    tours, and for sizes where even one tour per core exceeds the budget (TSP-10000) also a lower
+    iteration cap.  Returns the baseline dict, the oracle's tours/iterations and the cap it ran with."""
     from oracle import two_opt_oracle as orc
     n = pts.shape[1]
     threads = max(1, min(16, os.cpu_count() or 1, orc.max_threads()))
     pairs = (n - 1) * (n - 2) // 2
-    # about 10-30 s of CPU work: ~3e8 pair evaluations per core-second
-    per_tour = pairs * (n * 1.15)
-    want = int(max(threads, min(len(tours), (20.0 * 3.0e8 * threads) / per_tour)))
+    budget = 20.0 * 3.0e8 * threads                  # ~3e8 pair evaluations per core-second
+    est_sweeps = min(cap, int(n * 1.3) + 1)
+    want = int(max(threads, min(len(tours), budget / (pairs * est_sweeps))))
     want = max(tpi, (want // tpi) * tpi)
     want = min(want, len(tours))
+    cpu_cap = cap
+    rounds = (want + threads - 1) // threads         # tours each core solves one after another
+    if pairs * est_sweeps * rounds * threads > 1.5 * budget:
+        cpu_cap = max(1, int(budget / (pairs * rounds * threads)))
     sub_t = tours[:want]
     sub_p = pts[: (want + tpi - 1) // tpi]
     t0 = time.perf_counter()
     out, iters, sweeps = orc.solve(sub_p, sub_t, tours_per_instance=tpi, group_size=group,
-                                   max_iterations=cap, threads=threads)
+                                   max_iterations=cpu_cap, threads=threads)
     dt = time.perf_counter() - t0
+    capnote = "" if cpu_cap == cap else f", iteration cap lowered to {cpu_cap} for the sample"
     return {
         "value": float(sweeps.astype(np.int64).sum()) * pairs / dt,
         "unit": "pair-deltas/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"first {want} of {len(tours)} tours of the same batch, {dt:.1f} s, "
+        "sample": f"first {want} of {len(tours)} tours of the same batch{capnote}, {dt:.1f} s, "
                   f"{want / dt:.2f} tours/s, OpenMP over tours",
-        "tours_per_s": want / dt,
-    }, out, iters
+        "tours_per_s": want / dt if cpu_cap == cap else None,
+    }, out, iters, cpu_cap
 
 
 def main():
@@ -92,6 +99,8 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--max-iterations", type=int, default=5000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cluster-mode", type=int, default=-1,
+                    help="diagnostic: -1 automatic, 0 one workgroup per tour, k>=2 up to k workgroups per tour")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,7 +115,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # launched by torch.distributed.run (RANK set): the distributed path runs even at world size 1,
+    # so a 1-GPU box rehearses exactly the code the N-GPU launch executes
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -115,6 +127,7 @@ def main():
     from ml4tspbench_amd import _lib
     L = _lib.lib()
     L.tsp2opt_profile_enable(1)
+    L.tsp2opt_debug_cluster_mode(args.cluster_mode)
 
     np_dtype = np.float64 if args.dtype == "f64" else np.float32
     n, inst, tpi = CONFIGS[args.config]
@@ -125,21 +138,21 @@ def main():
     d_pts = torch.from_numpy(pts).to(dev)
     d_tours = torch.from_numpy(tours).to(dev)
     gather_t = gather_l = None
-    if world > 1:
+    if use_dist:
         gather_t = torch.empty((world * T, n + 1), dtype=torch.int64, device=dev)
         gather_l = torch.empty(world * T, dtype=torch.float64, device=dev)
 
     def step():
         res = amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi, group_size=group,
                                  max_iterations=args.max_iterations, want_lengths=True)
-        if world > 1:       # the only exchange of the path: final gather of tours and lengths
+        if use_dist:        # the only exchange of the path: final gather of tours and lengths
             dist.all_gather_into_tensor(gather_t, res.tours)
             dist.all_gather_into_tensor(gather_l, res.lengths)
         return res
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -157,7 +170,7 @@ def main():
             kern_ms.append((m.value, f.value))
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
         dt = float(tdt.item())
@@ -166,7 +179,7 @@ def main():
     iters = res.iterations
     my_pd = torch.tensor([float(sweeps.sum().item()) * pairs, float(T), float(iters.sum().item()),
                           float(iters.max().item())], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         mx = my_pd[3:].clone()
         dist.all_reduce(my_pd, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -226,15 +239,20 @@ def main():
         if gap is not None:
             out["fp32_vs_fp64"] = gap
         if not args.no_cpu:
-            cb, ref_out, ref_it = cpu_baseline(args.config, pts, tours, tpi, group, args.max_iterations)
+            cb, ref_out, ref_it, cpu_cap = cpu_baseline(args.config, pts, tours, tpi, group,
+                                                        args.max_iterations)
             k = len(ref_out)
-            same = bool(np.array_equal(res.tours[:k].cpu().numpy(), ref_out)
-                        and np.array_equal(res.iterations[:k].cpu().numpy(), ref_it))
+            chk = res
+            if cpu_cap != args.max_iterations:      # untimed GPU run of the sample at the sample's cap
+                chk = amd.two_opt_device(d_pts[: (k + tpi - 1) // tpi], d_tours[:k], tours_per_instance=tpi,
+                                         group_size=group, max_iterations=cpu_cap, want_lengths=False)
+            same = bool(np.array_equal(chk.tours[:k].cpu().numpy(), ref_out)
+                        and np.array_equal(chk.iterations[:k].cpu().numpy(), ref_it))
             cb["gpu_matches_oracle_on_sample"] = same
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

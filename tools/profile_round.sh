@@ -1,0 +1,31 @@
+#!/bin/bash
+# tools/profile_round.sh TAG [stage ...] -- evidence for profiles/: bench lines, rocprofv3 kernel
+# stats, PMC passes, phase breakdowns.  Stages: bench kt pmc configs variants phases dist (default all).
+# Everything lands in gpurun_out/TAG_*.  Run on the GPU box from the repo root.
+set -u
+TAG=${1:-rXX}; shift || true
+STAGES=${*:-bench kt pmc configs variants phases dist}
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out
+for st in $STAGES; do
+  echo "== stage $st"
+  case $st in
+  bench) timeout -k 10 200 python bench.py > $O/${TAG}_bench_tsp500.json 2> $O/${TAG}_bench_tsp500.err || exit 1 ;;
+  kt) timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -- python bench.py --steps 4 --warmup 1 --no-cpu > $O/${TAG}_kt.log 2>&1 || exit 1
+      cp $(find $O/${TAG}_kt -name '*kernel_stats.csv' | head -1) $O/${TAG}_kernel_stats.csv ;;
+  pmc) bash tools/pmc_passes.sh || exit 1
+       python tools/summarize_pmc.py > $O/${TAG}_pmc_summary.json || exit 1 ;;
+  configs) for c in tsp50 tsp100 tsp1000 tsp10000; do
+      echo "   bench $c"
+      timeout -k 10 250 python bench.py --config $c --steps 3 --warmup 1 > $O/${TAG}_bench_$c.json 2> $O/${TAG}_bench_$c.err || exit 1
+    done ;;
+  variants) timeout -k 10 200 python bench.py --mode grouped --no-cpu > $O/${TAG}_bench_tsp500_grouped.json 2>&1 || exit 1
+      timeout -k 10 200 python bench.py --dtype f32 --no-cpu > $O/${TAG}_bench_tsp500_f32.json 2>&1 || exit 1 ;;
+  phases) for c in tsp50 tsp100 tsp500 tsp1000; do
+      echo "   phases $c"
+      timeout -k 10 120 python tools/phase_breakdown.py $c > $O/${TAG}_phase_$c.txt 2>&1 || exit 1
+    done ;;
+  dist) timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu > $O/${TAG}_bench_dist1.json 2> $O/${TAG}_bench_dist1.err || exit 1 ;;
+  esac
+done
+echo profile_round done
