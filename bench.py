@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--max-iterations", type=int, default=5000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--instances", type=int, default=0, help="diagnostic: override the number of instances")
+    ap.add_argument("--tune", action="append", default=[], help="diagnostic: tsp2opt_debug_tune what=value")
     ap.add_argument("--cluster-mode", type=int, default=-1,
                     help="diagnostic: -1 automatic, 0 one workgroup per tour, k>=2 up to k workgroups per tour")
     args = ap.parse_args()
@@ -128,8 +130,13 @@ def main():
     L = _lib.lib()
     L.tsp2opt_profile_enable(1)
     L.tsp2opt_debug_cluster_mode(args.cluster_mode)
+    for kv in args.tune:                             # diagnostic knobs, e.g. --tune 0=1024
+        k_, v_ = kv.split("=")
+        L.tsp2opt_debug_tune(int(k_), int(v_))
 
     np_dtype = np.float64 if args.dtype == "f64" else np.float32
+    if args.instances > 0:
+        CONFIGS[args.config] = (CONFIGS[args.config][0], args.instances, CONFIGS[args.config][2])
     n, inst, tpi = CONFIGS[args.config]
     pts, tours, tpi = make_batch(args.config, 1234 + rank, np_dtype)   # seed 1234 (utils/args.py:27)
     group = tpi if args.mode == "grouped" and tpi > 1 else 1

@@ -43,6 +43,9 @@ SYMBOLS = (
     "tsp2opt_debug_phase_cycles",
     "tsp2opt_debug_sweep_only",
     "tsp2opt_debug_cluster_mode",
+    "tsp2opt_debug_cluster_inc",
+    "tsp2opt_debug_tune",
+    "tsp2opt_cluster_plan",
     "tsp2opt_last_error",
     "tsp2opt_version",
 )
@@ -90,6 +93,12 @@ def lib() -> ctypes.CDLL:
     L.tsp2opt_debug_sweep_only.restype = ctypes.c_int
     L.tsp2opt_debug_cluster_mode.argtypes = [i32]
     L.tsp2opt_debug_cluster_mode.restype = ctypes.c_int
+    L.tsp2opt_debug_cluster_inc.argtypes = [i32]
+    L.tsp2opt_debug_cluster_inc.restype = ctypes.c_int
+    L.tsp2opt_debug_tune.argtypes = [i32, i32]
+    L.tsp2opt_debug_tune.restype = ctypes.c_int
+    L.tsp2opt_cluster_plan.argtypes = [i32, i32, i64, i32, vp]
+    L.tsp2opt_cluster_plan.restype = ctypes.c_int
     L.tsp2opt_last_error.argtypes = []
     L.tsp2opt_last_error.restype = ctypes.c_char_p
     L.tsp2opt_version.argtypes = []

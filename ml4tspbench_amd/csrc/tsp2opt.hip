@@ -949,12 +949,17 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
 // the host launches at most one workgroup per CU, and every spin is bounded.
 struct CGeo {
     int n, nt;
-    int GP;                 // lane groups of the whole tour (stream B = group + GP)
+    int GP;                 // lane groups of the whole tour: group gp owns cyclic diagonals 2+8gp .. 9+8gp
+                            // (stream A the first four, stream B the next four)
     int CS, CR, CD;         // workgroups per tour = CR row bands x CD diagonal-group bands
     int GPw, NSw, MS;       // per workgroup: lane groups, row segments; macro steps per segment
     int Qw;                 // entries per sub-array of the column pair arrays
     int rowsw;              // row positions of the band = 4*NSw*MS
     int xlds;
+    int K, Ksh;             // macro steps per cache entry ("step group", power of two) and log2(4*K)
+    int NG;                 // step groups per unit = ceil(MS / K), <= 64
+    int inc;                // group-minimum cache + incremental sweeps (needs GPw*NSw <= nt)
+    int lcap;               // capacity of the changed-group list
     float eps2;
 };
 
@@ -984,6 +989,8 @@ struct CView {
     uint16_t* tour;
     v2f *Xq, *Yq, *Eq;      // column pair arrays, slot = u*Qw + local index
     float *RX, *RY, *RE;    // row band, natural order
+    float* Mc;              // filter minimum of every step group, Mc[group * units + unit], or null
+    uint16_t* list;         // ids (unit * NG + group) of the step groups the last reversal touched
     const T* X;
     double cx, cy, sc;
     int ilo;                // window group of local column index 0
@@ -1008,7 +1015,7 @@ __device__ void stage_c(const CView<T>& v, const CGeo& g, int tid, int lo, int h
     for (int k = tid; k < 4 * g.Qw; k += g.nt) {
         const int il = k >> 2, u = k & 3, sl = u * g.Qw + il;
         const int w = 4 * (v.ilo + il) + u;
-        const int pa = w % n, pb = (w + 4 * g.GP) % n;
+        const int pa = w % n, pb = (w + 4) % n;
         if (pa >= lo && pa <= hi) { float x, y; scaled_pos(v, pa, x, y); v.Xq[sl].x = x; v.Yq[sl].x = y; }
         if (pb >= lo && pb <= hi) { float x, y; scaled_pos(v, pb, x, y); v.Xq[sl].y = x; v.Yq[sl].y = y; }
         if (pa >= elo && pa <= ehi) {
@@ -1074,6 +1081,29 @@ __device__ __forceinline__ float macro_step_c(const v2f* Xq, const v2f* Yq, cons
     return mm;
 }
 
+// walk `count` consecutive macro steps of one unit starting at local row rl / column index col - 1
+// (Dc rebuilt from scratch); f(mm) receives the filter minimum of every macro step in order
+template <typename T, typename F>
+__device__ __forceinline__ void walk_c(const CView<T>& v, const CGeo& g, int rl, int col, int count, F&& f)
+{
+    v2f CX0[4], CY0[4], CX1[4], CY1[4], E0[4], E1[4], Dc[4];
+    load_block_c(v.Xq, v.Yq, v.Eq, g.Qw, col - 1, CX0, CY0, E0);
+    const float ax = v.RX[rl], ay = v.RY[rl];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Dc[q] = dist32x2(ax, ay, CX0[q], CY0[q]);
+    int m = 0;
+    for (; m + 1 < count; m += 2) {
+        f(macro_step_c(v.Xq, v.Yq, v.Eq, g.Qw, v.RX, v.RY, v.RE, rl, col, CX0, CY0, CX1, CY1, E0, E1, Dc));
+        f(macro_step_c(v.Xq, v.Yq, v.Eq, g.Qw, v.RX, v.RY, v.RE, rl + 4, col + 1, CX1, CY1, CX0, CY0, E1, E0, Dc));
+        rl += 8; col += 2;
+    }
+    if (m < count)
+        f(macro_step_c(v.Xq, v.Yq, v.Eq, g.Qw, v.RX, v.RY, v.RE, rl, col, CX0, CY0, CX1, CY1, E0, E1, Dc));
+}
+
+// Chunk ids of the cluster kernel: id = unit * NG + group, unit = sl * GPw + gpl (local row segment,
+// local lane group), group = K consecutive macro steps of the unit (K = 1 without the cache).
+// Full sweep of this workgroup's tile; the group minima go to the cache when there is one.
 template <typename T>
 __device__ __forceinline__ void filter_sweep_c(const CView<T>& v, const CGeo& g, int tid, float& a1,
                                                float& a2, unsigned& chunk)
@@ -1085,27 +1115,116 @@ __device__ __forceinline__ void filter_sweep_c(const CView<T>& v, const CGeo& g,
     for (int u = tid; u < units; u += g.nt) {
         const int gpl = u % g.GPw, sl = u / g.GPw;
         if (v.gp0 + gpl >= g.GP) continue;              // padding of the last diagonal band
-        int rl = 4 * sl * g.MS;
-        int col = sl * g.MS + gpl + 1;
-        v2f CX0[4], CY0[4], CX1[4], CY1[4], E0[4], E1[4], Dc[4];
-        load_block_c(v.Xq, v.Yq, v.Eq, g.Qw, col - 1, CX0, CY0, E0);
-        const float ax = v.RX[rl], ay = v.RY[rl];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Dc[q] = dist32x2(ax, ay, CX0[q], CY0[q]);
-        unsigned id = (unsigned)u * (unsigned)g.MS;
-        int m = 0;
-        for (; m + 1 < g.MS; m += 2) {
-            float mm = macro_step_c(v.Xq, v.Yq, v.Eq, g.Qw, v.RX, v.RY, v.RE, rl, col, CX0, CY0, CX1, CY1, E0, E1, Dc);
-            track(mm, id, a1, a2, chunk);
-            mm = macro_step_c(v.Xq, v.Yq, v.Eq, g.Qw, v.RX, v.RY, v.RE, rl + 4, col + 1, CX1, CY1, CX0, CY0, E1, E0, Dc);
-            track(mm, id + 1, a1, a2, chunk);
-            rl += 8; col += 2; id += 2;
-        }
-        if (m < g.MS) {
-            const float mm = macro_step_c(v.Xq, v.Yq, v.Eq, g.Qw, v.RX, v.RY, v.RE, rl, col, CX0, CY0, CX1, CY1, E0, E1, Dc);
-            track(mm, id, a1, a2, chunk);
+        unsigned id = (unsigned)u * (unsigned)g.NG;
+        float* mc = v.Mc ? v.Mc + u : nullptr;
+        float gm = INFINITY;
+        int k = 0;
+        const int K = g.K;
+        walk_c(v, g, 4 * sl * g.MS, sl * g.MS + 2 * gpl + 1, g.MS, [&](float mm) {
+            gm = __builtin_fminf(gm, mm);
+            if (++k == K) {
+                if (mc) { *mc = gm; mc += units; }
+                track(gm, id, a1, a2, chunk);
+                gm = INFINITY; k = 0; ++id;
+            }
+        });
+        if (k) {                                        // last, shorter group
+            if (mc) *mc = gm;
+            track(gm, id, a1, a2, chunk);
         }
     }
+}
+
+// filter minimum of one step group, from scratch (incremental sweeps)
+template <typename T>
+__device__ __forceinline__ float group_min_c(const CView<T>& v, const CGeo& g, int u, int grp)
+{
+    const int gpl = u % g.GPw, sl = u / g.GPw;
+    const int m0 = grp * g.K;
+    const int cnt = g.MS - m0 < g.K ? g.MS - m0 : g.K;
+    float gm = INFINITY;
+    walk_c(v, g, 4 * (sl * g.MS + m0), sl * g.MS + 2 * gpl + 1 + m0, cnt,
+           [&](float mm) { gm = __builtin_fminf(gm, mm); });
+    return gm;
+}
+
+// Filter sweep of one iteration of the cluster kernel.  `last` = the reversal applied since the
+// previous sweep or kFullSweep.  With the cache, only step groups that read a changed window
+// position (coordinates last.i+1..last.j, edges last.i..last.j, any cyclic copy) are recomputed:
+// each lane marks the touched groups of its own unit in closed form (rows, columns), the ids are compacted into a list and processed evenly by all lanes, then
+// every lane reduces the cached minima of its unit exactly as the full sweep would.
+template <typename T>
+__device__ __forceinline__ void sweep_c(const CView<T>& v, const CGeo& g, int tid, unsigned last,
+                                        float& a1, float& a2, unsigned& chunk)
+{
+    Ctl* ctl = v.ctl;
+    const int units = g.GPw * g.NSw;
+    bool full = !g.inc || last == kFullSweep;
+    if (!full) {
+        const int i = (int)(last >> 16), j = (int)(last & 0xffffu);
+        const int gpl = tid % g.GPw, sl = tid / g.GPw;
+        const bool own = tid < units && v.gp0 + gpl < g.GP;
+        unsigned long long mask = 0ull;
+        if (own) {
+            const int rb = v.rbase + 4 * sl * g.MS;                 // window position of the unit's first row
+            const int ca = rb + 2 + 8 * (v.gp0 + gpl);              // ... of its first column (stream A)
+            const int wmax = ca + (g.NG << g.Ksh) + 8;
+            // group q reads rows [rb + Sq, rb + Sq + S], columns [ca + Sq, ca + Sq + S + 7], S = 4K
+            for (int lo = i, hi = j; lo <= wmax; lo += g.n, hi += g.n) {
+                mask |= bit_range((lo - rb - 1) >> g.Ksh, (hi - rb) >> g.Ksh, g.NG);
+                mask |= bit_range((lo - ca - 8) >> g.Ksh, (hi - ca) >> g.Ksh, g.NG);
+            }
+        }
+        unsigned wtotal = 0;
+        for (int q = 0; q < g.NG; ++q) wtotal += (unsigned)__popcll(__ballot((mask >> q) & 1ull));
+        unsigned base = 0;
+        if (wtotal) {
+            if ((tid & 63) == 0) base = atomicAdd(&ctl->nlist, wtotal);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            for (int q = 0; q < g.NG; ++q) {
+                const unsigned long long b = __ballot((mask >> q) & 1ull);
+                if ((mask >> q) & 1ull) {
+                    const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+                    if (pos < (unsigned)g.lcap) v.list[pos] = (uint16_t)(tid * g.NG + q);
+                }
+                base += (unsigned)__popcll(b);
+            }
+        }
+        __syncthreads();
+        const unsigned nl = ctl->nlist;
+        if (nl > (unsigned)g.lcap) {
+            full = true;                                    // most of the tile moved: plain sweep
+        } else {
+            __builtin_amdgcn_s_setprio(0);
+            for (unsigned t = (unsigned)tid; t < nl; t += (unsigned)g.nt) {
+                const int id = v.list[t];
+                const int u = id / g.NG, q = id - u * g.NG;
+                v.Mc[q * units + u] = group_min_c(v, g, u, q);
+            }
+            __builtin_amdgcn_s_setprio(3);
+        }
+        __syncthreads();
+        if (tid == 0) ctl->nlist = 0;
+        if (!full) {
+            a1 = INFINITY;
+            a2 = INFINITY;
+            chunk = 0;
+            if (own) {
+                unsigned id = (unsigned)tid * (unsigned)g.NG;
+                const float* mc = v.Mc + tid;
+                for (int q = 0; q < g.NG; ++q) {
+                    track(*mc, id, a1, a2, chunk);
+                    ++id;
+                    mc += units;
+                }
+            }
+            return;
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    filter_sweep_c(v, g, tid, a1, a2, chunk);
+    __builtin_amdgcn_s_setprio(3);
 }
 
 template <typename T>
@@ -1117,16 +1236,15 @@ __device__ __forceinline__ double exact_delta_c(const CView<T>& v, int i, int j)
     return exact_delta(w, i, j);
 }
 
-// exact value of pair `pr` (0..31) of local macro step `id`; false for padding units
+// exact value of pair `pr` (0..31) of macro step `m` of local unit `u`; false for padding units
 template <typename T>
-__device__ __forceinline__ bool eval_chunk_pair_c(const CView<T>& v, const CGeo& g, unsigned id, int pr,
+__device__ __forceinline__ bool eval_chunk_pair_c(const CView<T>& v, const CGeo& g, int u, int m, int pr,
                                                   double& e, unsigned& idx)
 {
-    const int u = (int)(id / (unsigned)g.MS), m = (int)(id % (unsigned)g.MS);
     const int gpl = u % g.GPw, sl = u / g.GPw;
     const int gp = v.gp0 + gpl;
     if (gp >= g.GP) return false;
-    const int gi = gp + (pr >> 4) * g.GP;
+    const int gi = 2 * gp + (pr >> 4);
     const int r0 = 4 * ((v.rs0 + sl) * g.MS + m);
     const int c0 = r0 + 2 + 4 * gi;
     const int a = (pr >> 2) & 3, q = pr & 3;
@@ -1139,17 +1257,15 @@ __device__ __forceinline__ bool eval_chunk_pair_c(const CView<T>& v, const CGeo&
 
 // best move of this workgroup's tile: e = min(0, min exact delta), idx packed; valid in all threads
 template <typename T>
-__device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool first_wg, double& e,
-                               unsigned& idx, Prof& pf)
+__device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool first_wg, unsigned last,
+                               double& e, unsigned& idx, Prof& pf)
 {
     Ctl* ctl = v.ctl;
     float a1, a2;
     unsigned chunk;
     unsigned long long t0 = 0;
     if (pf.on) t0 = clock64();
-    __builtin_amdgcn_s_setprio(0);
-    filter_sweep_c(v, g, tid, a1, a2, chunk);
-    __builtin_amdgcn_s_setprio(3);
+    sweep_c(v, g, tid, last, a1, a2, chunk);
     if (pf.on) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
     const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
     const float wm = wave_min(a1);
@@ -1168,11 +1284,16 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
         while (cmask) {
             const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)cmask) - 1);
             cmask &= cmask - 1;
-            const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)chunk, src);
-            if (lane < 32) {
+            const int id = __builtin_amdgcn_readlane((int)chunk, src);
+            const int u = id / g.NG, m0 = (id - u * g.NG) * g.K;       // the K macro steps of the group
+            for (int pp = lane; pp < 32 * g.K; pp += 64) {
+                const int m = m0 + (pp >> 5);
                 double d;
                 unsigned di;
-                if (eval_chunk_pair_c(v, g, id, lane, d, di) && better(d, di, e, idx)) { e = d; idx = di; }
+                if (m < g.MS && eval_chunk_pair_c(v, g, u, m, pp & 31, d, di) && better(d, di, e, idx)) {
+                    e = d;
+                    idx = di;
+                }
             }
         }
         if (first_wg && tid == 32) {        // the pair (0, n-1), once per tour
@@ -1202,7 +1323,8 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
         for (long long k = tid; k < total; k += g.nt) {
             double d;
             unsigned di;
-            if (eval_chunk_pair_c(v, g, (unsigned)(k >> 5), (int)(k & 31), d, di) && better(d, di, e, idx)) {
+            const int ms = (int)(k >> 5);
+            if (eval_chunk_pair_c(v, g, ms / g.MS, ms % g.MS, (int)(k & 31), d, di) && better(d, di, e, idx)) {
                 e = d;
                 idx = di;
             }
@@ -1299,10 +1421,17 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
     v.RX = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * (size_t)(g.rowsw + 8));
     v.RY = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * (size_t)(g.rowsw + 8));
     v.RE = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * (size_t)(g.rowsw + 8));
+    v.Mc = nullptr;
+    v.list = nullptr;
+    if (g.inc) {
+        const size_t groups = (size_t)g.GPw * g.NSw * g.NG;
+        v.Mc = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * groups);
+        v.list = reinterpret_cast<uint16_t*>(smem + off); off += align16(sizeof(uint16_t) * (size_t)g.lcap);
+    }
     T* xl = reinterpret_cast<T*>(smem + off);
     v.rs0 = cr * g.NSw;
     v.gp0 = cd * g.GPw;
-    v.ilo = v.rs0 * g.MS + v.gp0;
+    v.ilo = v.rs0 * g.MS + 2 * v.gp0;
     v.rbase = 4 * v.rs0 * g.MS;
     Ctl* ctl = v.ctl;
     unsigned* cs = p.csync + (size_t)cluster * (size_t)p.cstride;
@@ -1310,6 +1439,7 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
 
     for (int64_t tk = cluster; tk < p.num_tours; tk += p.num_clusters) {
         __syncthreads();
+        if (tid == 0) ctl->nlist = 0;
         const T* X = reinterpret_cast<const T*>(p.points) + (size_t)(tk / p.tpi) * (size_t)n * 2;
         int64_t* gt = p.tours + (size_t)tk * (size_t)(n + 1);
         // ---- stage + validate (every workgroup of the cluster computes the same flags) -------
@@ -1377,10 +1507,11 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
         bool aborted = false;
         Prof pf{p.stamps != nullptr, 0, 0, 0};
         unsigned long long t_x = 0, t_tour = pf.on ? clock64() : 0;
+        unsigned last = kFullSweep;             // reversal applied since the previous sweep
         for (;;) {
             double e;
             unsigned idx, fl = 0;
-            find_best_tile(v, g, tid, wc == 0, e, idx, pf);
+            find_best_tile(v, g, tid, wc == 0, last, e, idx, pf);
             ++sweeps;
             unsigned long long tb = pf.on ? clock64() : 0;
             unsigned myflags = 0;
@@ -1400,6 +1531,7 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
             __syncthreads();
             stage_c(v, g, tid, i + 1, j, i, j);
             __syncthreads();
+            last = idx;
             if (pf.on) pf.apply += clock64() - tb;
             ++it;
             if (it >= p.max_iter) { st |= TSP2OPT_ST_CAPPED; break; }        // two_opt.py:47
@@ -1662,6 +1794,9 @@ struct Plan {
 constexpr size_t kLdsMax = 160 * 1024;
 const int kQClasses[] = {16, 32, 64, 128, 256, 512};
 
+int g_force_nt = 0;         // diagnostic: threads per workgroup of the single-workgroup plan
+int g_lcap16 = 8;           // diagnostic: changed-group list capacity of the cluster kernel, in 1/16 of the groups
+
 Plan make_plan(int n, int dtype)
 {
     Plan pl{};
@@ -1673,6 +1808,7 @@ Plan make_plan(int n, int dtype)
     const size_t xbytes = (size_t)n * 2 * tsz;
     // threads per workgroup: about 500 pairs per lane per sweep
     int nt = n <= 160 ? 64 : n <= 320 ? 128 : n <= 640 ? 256 : n <= 1280 ? 512 : 1024;
+    if (g_force_nt) nt = g_force_nt;
     g.nt = nt;
     g.qclass = 0;
     size_t cache = 0;
@@ -1790,6 +1926,8 @@ struct CPlan {
 };
 
 // geometry of the cluster kernel for at most `cs_cap` workgroups per tour
+int g_cluster_inc = 1;      // 0: cluster kernel without the group-minimum cache (diagnostic)
+
 CPlan make_cluster_plan(int n, int dtype, int cs_cap, bool smallest)
 {
     CPlan best{};
@@ -1823,15 +1961,34 @@ CPlan make_cluster_plan(int n, int dtype, int cs_cap, bool smallest)
                 const int units = GPw * NSw;
                 const int passes = (units + nt - 1) / nt;
                 const int wps = (nt / 64 + 3) / 4;      // waves per SIMD
-                const double t_iter = 0.4 * MS * passes * wps + 12.0 + 0.15 * cs;
-                const double cost = smallest ? t_iter * cs : t_iter;    // total WG-time vs latency
-                const int Qw = NSw * MS + GPw + 3;
+                const int Qw = NSw * MS + 2 * GPw + 3;
                 const int rowsw = 4 * NSw * MS;
                 size_t lds = base + (size_t)Qw * 96 + 3 * align16(sizeof(float) * (size_t)(rowsw + 8));
-                if (lds > kLdsMax || cost >= best_cost) continue;
+                if (lds > kLdsMax) continue;
+                // group-minimum cache: the finest granularity K (macro steps per entry) that fits
+                int K = 0, Ksh = 0, NG = MS, lcap = 0;
+                size_t cache = 0;
+                if (units <= nt && g_cluster_inc) {
+                    for (int k = 1, sh = 2; k <= 64; k *= 2, ++sh) {
+                        const int ng = (MS + k - 1) / k;
+                        const size_t groups = (size_t)units * ng;
+                        const size_t cap = groups * (size_t)g_lcap16 / 16 + 1;
+                        const size_t need = align16(4 * groups) + align16(2 * cap);
+                        if (ng <= 64 && (size_t)nt * ng <= 65535 && lds + need <= kLdsMax) {
+                            K = k; Ksh = sh; NG = ng; lcap = (int)cap; cache = need;
+                            break;
+                        }
+                    }
+                }
+                // measured: incremental sweeps recompute a little under half of the pairs
+                const double t_iter = (K ? 0.55 : 1.0) * 0.4 * MS * passes * wps + 12.0 + 0.15 * cs;
+                const double cost = smallest ? t_iter * cs : t_iter;    // total WG-time vs latency
+                if (cost >= best_cost) continue;
+                lds += cache;
                 CGeo g{};
                 g.n = n; g.nt = nt; g.GP = GP; g.CS = cs; g.CR = cr; g.CD = cd;
                 g.GPw = GPw; g.NSw = NSw; g.MS = MS; g.Qw = Qw; g.rowsw = rowsw;
+                g.K = K ? K : 1; g.Ksh = K ? Ksh : 2; g.NG = NG; g.inc = K ? 1 : 0; g.lcap = lcap;
                 g.eps2 = dtype == TSP2OPT_DTYPE_F64 ? 2.0f * 0x1p-16f : 2.0f * 0x1p-15f;
                 g.xlds = 0;
                 if (lds + align16(xbytes) <= kLdsMax) { g.xlds = 1; lds += align16(xbytes); }
@@ -1863,6 +2020,19 @@ int launch_cluster(CParams p, const CPlan& cp, int cus, hipStream_t stream)
 }
 
 int g_cluster_mode = -1;    // -1 auto, 0 never, >= 2 force that many workgroups per tour (tests)
+
+// few tours (or N beyond one workgroup's LDS): several workgroups per tour; !ok = one workgroup per tour
+CPlan choose_cluster(int n, int dtype, int64_t num_tours, int cus, const Plan& pl)
+{
+    int cap = (int)std::min<int64_t>(64, cus / std::max<int64_t>(1, num_tours));
+    bool smallest = false;
+    if (g_cluster_mode >= 2) cap = std::min(g_cluster_mode, cus);
+    else if (pl.g.qclass == 0 && cap < 2) { cap = 64; smallest = true; }   // tiling for LDS only
+    else if (pl.g.qclass != 0 && (n < 700 || cap < 3)) cap = 0;
+    // (small tours are not worth a barrier; with two workgroups per tour the one-workgroup kernel with
+    //  its finer incremental sweeps is faster even on half the CUs: TSP-1000 x 128, 26.9 vs 35 ms)
+    return make_cluster_plan(n, dtype, cap, smallest);
+}
 
 template <typename T>
 int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* sweeps_out,
@@ -1911,12 +2081,7 @@ int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* swe
     if (group_size == 1 && g_cluster_mode != 0 && g_dbg_sweeps == 0) {
         int cus = 0;
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-        int cap = (int)std::min<int64_t>(64, cus / std::max<int64_t>(1, num_tours));
-        bool smallest = false;
-        if (g_cluster_mode >= 2) cap = std::min(g_cluster_mode, cus);
-        else if (pl.g.qclass == 0 && cap < 2) { cap = 64; smallest = true; }   // tiling for LDS only
-        else if (pl.g.qclass != 0 && n < 700) cap = 0;             // small tours: not worth a barrier
-        cp = make_cluster_plan(n, dtype, cap, smallest);
+        cp = choose_cluster(n, dtype, num_tours, cus, pl);
         if (cp.ok) {
             CParams c{};
             c.points = points; c.tours = tours; c.iters = p.iters; c.work_sweeps = p.work_sweeps;
@@ -2177,6 +2342,34 @@ extern "C" int tsp2opt_debug_sweep_only(int32_t sweeps)
 extern "C" int tsp2opt_debug_cluster_mode(int32_t mode)
 {
     g_cluster_mode = mode;
+    return 0;
+}
+
+extern "C" int tsp2opt_debug_cluster_inc(int32_t on)
+{
+    g_cluster_inc = on ? 1 : 0;
+    return 0;
+}
+
+extern "C" int tsp2opt_debug_tune(int32_t what, int32_t value)
+{
+    if (what == 0) g_force_nt = value;
+    else if (what == 1) g_lcap16 = value < 1 ? 1 : value > 16 ? 16 : value;
+    else return fail(TSP2OPT_E_ARG, "unknown tuning knob");
+    return 0;
+}
+
+extern "C" int tsp2opt_cluster_plan(int32_t n, int32_t dtype, int64_t num_tours, int32_t cus, int32_t* out12)
+{
+    if (n < 1 || n > TSP2OPT_MAX_N || num_tours < 1 || cus < 1 || !out12) return fail(TSP2OPT_E_ARG, "bad argument");
+    if (dtype != TSP2OPT_DTYPE_F32 && dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
+    const Plan pl = make_plan(n, dtype);
+    const CPlan cp = g_cluster_mode == 0 ? CPlan{} : choose_cluster(n, dtype, num_tours, cus, pl);
+    for (int k = 0; k < 12; ++k) out12[k] = 0;
+    if (!cp.ok) return 0;
+    out12[0] = cp.g.CS; out12[1] = cp.g.CR; out12[2] = cp.g.CD; out12[3] = cp.g.nt;
+    out12[4] = cp.g.GPw; out12[5] = cp.g.NSw; out12[6] = cp.g.MS; out12[7] = (int32_t)cp.lds;
+    out12[8] = cp.g.inc; out12[9] = cp.g.K; out12[10] = cp.g.NG; out12[11] = cp.g.xlds;
     return 0;
 }
 

@@ -146,6 +146,8 @@ CLUSTER_CASES = [
     (500, 3, np.float64, 5000, 16), (500, 2, np.float64, 5000, 2), (777, 2, np.float64, 5000, 0),
     (1000, 4, np.float64, 5000, 0), (1000, 1, np.float32, 5000, 0), (1500, 1, np.float64, 300, 32),
     (3000, 2, np.float64, 60, 0), (5000, 1, np.float64, 40, 0),
+    # coarse cache entries (K > 1 macro steps per entry: LDS-limited geometries)
+    (2000, 2, np.float64, 150, 2), (2500, 1, np.float32, 120, 3), (6000, 1, np.float64, 30, 8),
 ]
 
 
