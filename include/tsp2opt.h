@@ -186,12 +186,14 @@ int tsp2opt_debug_cluster_mode(int32_t mode);
 int tsp2opt_debug_cluster_inc(int32_t on);
 /* Diagnostic tuning knobs (benchmark sweeps only): what = 0: threads per workgroup of the
  * one-workgroup-per-tour kernel (0 = automatic); what = 1: capacity of the cluster kernel's
- * changed-group list in sixteenths of all groups (default 8). */
+ * changed-group list in sixteenths of all groups (default 8); what = 2: tiles a lane must own for the
+ * tile-minimum cache to be used (default 2); what = 3: cluster kernel variant, 0 automatic, 1 band
+ * kernel only, 2 full-window kernel only. */
 int tsp2opt_debug_tune(int32_t what, int32_t value);
 /* Geometry the library would pick for `num_tours` tours of n nodes on a device with `cus` compute
  * units when several workgroups share a tour (host-only, for logs and tests):
- * out[0]=workgroups per tour (0: one workgroup per tour, tsp2opt_plan applies), out[1]=row bands,
- * out[2]=diagonal bands, out[3]=threads, out[4]=lane groups, out[5]=row segments, out[6]=macro steps,
+ * out[0]=workgroups per tour (0: one workgroup per tour, tsp2opt_plan applies), out[1]=row bands
+ * (0: full-window cluster, lane groups interleaved over the workgroups), out[2]=diagonal bands, out[3]=threads, out[4]=lane groups, out[5]=row segments, out[6]=macro steps,
  * out[7]=LDS bytes, out[8]=incremental sweeps, out[9]=macro steps per cache entry, out[10]=cache
  * entries per lane, out[11]=exact coordinates in LDS */
 int tsp2opt_cluster_plan(int32_t n, int32_t dtype, int64_t num_tours, int32_t cus, int32_t* out12);

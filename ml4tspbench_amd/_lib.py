@@ -119,3 +119,15 @@ def plan(n: int, dtype: int = DTYPE_F64, device: int = -1) -> dict:
     keys = ("threads", "filter_class", "lds_bytes", "row_segments", "diag_groups", "macro_steps",
             "workgroups_per_cu")
     return dict(zip(keys, list(out)))
+
+
+def cluster_plan(n: int, dtype: int, num_tours: int, cus: int = 256) -> dict:
+    """Geometry tsp2opt_solve would use when several workgroups share a tour (0 workgroups per tour:
+    one workgroup per tour, see plan()); row_bands == 0 marks the full-window cluster kernel."""
+    out = (ctypes.c_int32 * 12)()
+    check(lib().tsp2opt_cluster_plan(n, dtype, num_tours, cus, ctypes.cast(out, ctypes.c_void_p)),
+          "tsp2opt_cluster_plan")
+    keys = ("workgroups_per_tour", "row_bands", "diag_bands", "threads", "lane_groups", "row_segments",
+            "macro_steps", "lds_bytes", "incremental", "steps_per_cache_entry", "cache_entries_per_lane",
+            "exact_coords_in_lds")
+    return dict(zip(keys, list(out)))

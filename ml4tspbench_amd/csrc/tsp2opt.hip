@@ -64,6 +64,8 @@ struct Geo {                          // launch geometry of the filter sweep (ho
     int nt;                           // threads per workgroup
     int qclass;                       // 0: exact-only kernel; else sub-array stride Q
     int GP;                           // lane groups; group gp owns cyclic diagonals 2+8gp .. 9+8gp
+    int CS, wc;                       // workgroups sharing the tour (1 = none) and this workgroup's index
+    int GPl;                          // lane groups walked by this workgroup: gp = wc + CS*gpl, gpl < GPl
     int G;                            // = 2 * GP groups of 4 diagonals (cyclic diagonals 2..4G+1)
     int NS;                           // row segments
     int MS;                           // macro steps (4 rows) per segment, even: MS/2 tiles of 8 rows
@@ -91,6 +93,9 @@ struct Params {
     long long time_limit_ticks;       // wall_clock64 ticks, 0 = none
     unsigned long long* stamps;       // optional phase timers (tsp2opt_debug_phase_cycles), else null
     int dbg_sweeps;                   // > 0: diagnostic, run only this many filter sweeps per tour
+    unsigned* csync;                  // CS > 1: per cluster `cstride` dwords: [0] arrivals, [1] abort, [16..] slots
+    int cstride;
+    int num_clusters;
     Geo g;
 };
 
@@ -320,11 +325,11 @@ __device__ __forceinline__ void track(float mm, unsigned id, float& a1, float& a
     a1 = fminf(a1, mm);
 }
 
-// Tile ids: id = (rq << 8) | gp, rq = 8-row block of the whole window (segment s of unit
-// u = s * GP + gp covers rq = s*MS/2 .. (s+1)*MS/2 - 1), gp = lane group (< 256); the cached minimum
-// of the tile sits at Mc[rq * GP + gp].
+// Tile ids: id = (rq << 8) | gpl, rq = 8-row block of the whole window (segment s of unit
+// u = s * GPl + gpl covers rq = s*MS/2 .. (s+1)*MS/2 - 1), gpl = this workgroup's lane group (< 256,
+// global lane group gp = wc + CS * gpl); the cached minimum of the tile sits at Mc[rq * GPl + gpl].
 // Full sweep: every lane walks its own unit; the tile minima go to the cache when there is one.
-template <int Q>
+template <int Q, bool CL>
 __device__ __forceinline__ void filter_sweep(const v2f* Xq, const v2f* Yq, const v2f* Eq, float* Mc,
                                              const Geo& g, int tid, float& a1, float& a2,
                                              unsigned& chunk)
@@ -332,9 +337,13 @@ __device__ __forceinline__ void filter_sweep(const v2f* Xq, const v2f* Yq, const
     a1 = INFINITY;
     a2 = INFINITY;
     chunk = 0;
-    const int units = g.GP * g.NS, MS2 = g.MS >> 1;
+    const int units = g.GPl * g.NS, MS2 = g.MS >> 1;
     for (int u = tid; u < units; u += g.nt) {
-        const int gp = u % g.GP, s = u / g.GP;
+        const int gpl = u % g.GPl, s = u / g.GPl;
+        const int gp = CL ? g.wc + g.CS * gpl : gpl;
+        if constexpr (CL) {
+            if (gp >= g.GP) continue;                       // padding of the last workgroups
+        }
         int rq = s * MS2;
         int cb = rq + gp;
         v2f CX0[4], CY0[4], CX1[4], CY1[4], E0[4], E1[4], Dc[4];
@@ -342,12 +351,12 @@ __device__ __forceinline__ void filter_sweep(const v2f* Xq, const v2f* Yq, const
         const float ax = Xq[rq].x, ay = Yq[rq].x;           // P[r0]
 #pragma unroll
         for (int q = 0; q < 4; ++q) Dc[q] = dist32x2(ax, ay, CX0[q], CY0[q]);
-        unsigned id = ((unsigned)rq << 8) | (unsigned)gp;
-        float* mc = Mc ? Mc + rq * g.GP + gp : nullptr;
+        unsigned id = ((unsigned)rq << 8) | (unsigned)gpl;
+        float* mc = Mc ? Mc + rq * g.GPl + gpl : nullptr;
         for (int m2 = 0; m2 < MS2; ++m2) {
             float mm = macro_step<Q, 0>(Xq, Yq, Eq, rq, cb, CX0, CY0, CX1, CY1, E0, E1, Dc);
             mm = __builtin_fminf(mm, macro_step<Q, 1>(Xq, Yq, Eq, rq, cb, CX1, CY1, CX0, CY0, E1, E0, Dc));
-            if (mc) { *mc = mm; mc += g.GP; }
+            if (mc) { *mc = mm; mc += g.GPl; }
             track(mm, id, a1, a2, chunk);
             ++rq; ++cb; id += 256u;
         }
@@ -378,7 +387,8 @@ __device__ __forceinline__ unsigned long long bit_range(int a, int b, int M)
 }
 
 struct Unit {               // the lane's own unit, fixed for the whole kernel
-    int gp;                 // lane group, or -1 when the lane owns no unit
+    int gp;                 // lane group (of the whole tour), or -1 when the lane owns no unit
+    int gpl;                // its index among this workgroup's lane groups
     int rq0;                // first 8-row block of its row segment
 };
 
@@ -388,7 +398,7 @@ struct Unit {               // the lane's own unit, fixed for the whole kernel
 // touched tiles in closed form, the ids are compacted into a list (ballot per row block, one LDS
 // atomic per wave), the list is processed evenly by all lanes, then every lane reduces its own
 // cached tile minima exactly as the full sweep would.
-template <int Q, typename T>
+template <int Q, bool CL, typename T>
 __device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, const Unit& un,
                                       unsigned last, float& a1, float& a2, unsigned& chunk)
 {
@@ -417,7 +427,7 @@ __device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, c
                     const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32),
                                                     __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
                     if (pos < (unsigned)g.lcap)
-                        v.list[pos] = (uint16_t)(((unsigned)(un.rq0 + m2) << 8) | (unsigned)un.gp);
+                        v.list[pos] = (uint16_t)(((unsigned)(un.rq0 + m2) << 8) | (unsigned)un.gpl);
                 }
                 base += (unsigned)__popcll(b);
             }
@@ -430,8 +440,8 @@ __device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, c
             __builtin_amdgcn_s_setprio(0);
             for (unsigned t = (unsigned)tid; t < nl; t += (unsigned)g.nt) {
                 const unsigned id = v.list[t];
-                const int rq = (int)(id >> 8), gp = (int)(id & 255u);
-                v.Mc[rq * g.GP + gp] = tile_min<Q>(v.Xq, v.Yq, v.Eq, rq, gp);
+                const int rq = (int)(id >> 8), gpl = (int)(id & 255u);
+                v.Mc[rq * g.GPl + gpl] = tile_min<Q>(v.Xq, v.Yq, v.Eq, rq, g.wc + g.CS * gpl);
             }
             __builtin_amdgcn_s_setprio(3);
         }
@@ -442,19 +452,19 @@ __device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, c
             a2 = INFINITY;
             chunk = 0;
             if (un.gp >= 0) {
-                unsigned id = ((unsigned)un.rq0 << 8) | (unsigned)un.gp;
-                const float* mc = v.Mc + un.rq0 * g.GP + un.gp;
+                unsigned id = ((unsigned)un.rq0 << 8) | (unsigned)un.gpl;
+                const float* mc = v.Mc + un.rq0 * g.GPl + un.gpl;
                 for (int m2 = 0; m2 < MS2; ++m2) {
                     track(*mc, id, a1, a2, chunk);
                     id += 256u;
-                    mc += g.GP;
+                    mc += g.GPl;
                 }
             }
             return;
         }
     }
     __builtin_amdgcn_s_setprio(0);
-    filter_sweep<Q>(v.Xq, v.Yq, v.Eq, g.inc ? v.Mc : nullptr, g, tid, a1, a2, chunk);
+    filter_sweep<Q, CL>(v.Xq, v.Yq, v.Eq, g.inc ? v.Mc : nullptr, g, tid, a1, a2, chunk);
     __builtin_amdgcn_s_setprio(3);
 }
 
@@ -462,7 +472,7 @@ __device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, c
 __device__ __forceinline__ void tile_pair(const Geo& g, unsigned id, int pr, int& rw, int& cw)
 {
     rw = 8 * (int)(id >> 8) + (pr >> 3);
-    cw = rw + 2 + 8 * (int)(id & 255u) + (pr & 7);
+    cw = rw + 2 + 8 * (g.wc + g.CS * (int)(id & 255u)) + (pr & 7);
 }
 
 // exact value of pair `pr` of tile `id`; returns packed index
@@ -499,7 +509,9 @@ __device__ __forceinline__ void filter_chunk_pair(const View<T>& v, const Geo& g
 // Returns in every thread: e = min(0, min valid delta), idx = packed (i,j) or kNoMove.
 // `need_exact_sign`: the caller needs the exact sign of a non-improving minimum (coupled-mode
 // continuation); otherwise a minimum proven >= -1e-6 by the filter alone ends the search.
-template <typename T, int Q>
+// CL (several workgroups per tour): this workgroup's tiles only, always exact (the result is compared
+// with the other workgroups' results), no fp32-only shortcut.
+template <typename T, int Q, bool CL>
 __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& un, bool need_exact_sign,
                           unsigned last, double& e, unsigned& idx, Prof& pf)
 {
@@ -516,7 +528,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& u
         // everything outside the sweep arithmetic is a latency chain that idles most of the
         // workgroup: it runs at high issue priority (set inside sweep()) so that the other
         // workgroups' sweeps on this SIMD do not stretch it
-        sweep<Q>(v, g, tid, un, last, a1, a2, chunk);
+        sweep<Q, CL>(v, g, tid, un, last, a1, a2, chunk);
         if (pf.on) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
         const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
         const float wm = wave_min(a1);
@@ -528,79 +540,87 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& u
         const unsigned long long cmask0 = __ballot(a1 <= thr);
         int amb = __ballot(a2 <= thr) != 0ull || __popcll(cmask0) > 8;
 
-        // ---- stage 1, fp32 only.  Every pair whose exact delta can be the argmin has a filter
-        // value <= m + 2 eps and sits in a candidate macro step.  Re-evaluate those steps pair by
-        // pair (lanes 0..31) in fp32: if exactly ONE pair of the whole tour is inside the window it
-        // IS the reference's argmin, and if its value is below -1e-6 by more than eps the move is
-        // certain without any exact arithmetic.  Likewise a window that lies above -1e-6 + eps
-        // proves convergence.  Anything else falls through to the exact stage.
-        const float thr_scale = (float)(1.0e-6 * ctl->sc);
-        const float eps = 0.625f * g.eps2;                  // eps2 = 2 eps; 25 % extra margin
-        float fd = INFINITY;
-        unsigned fidx = 0xffffffffu;
-        bool multi = false;
-        if (!amb) {
-            unsigned long long cm = cmask0;
-            while (cm) {
-                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)cm) - 1);
-                cm &= cm - 1;
-                const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)chunk, src);
-                float d;
-                unsigned di;
-                filter_chunk_pair<Q>(v, g, id, lane, d, di);
-                if (d <= thr) {
-                    multi = multi || (fidx != 0xffffffffu && fidx != di);
-                    if (d < fd || (d == fd && di < fidx)) { fd = d; fidx = di; }
+        if constexpr (CL) {
+            if (lane == 0) ctl->pAmb[wv] = amb;
+            __syncthreads();
+            int fl = 0;
+            for (int w = 0; w < nw; ++w) fl |= ctl->pAmb[w];
+            amb = fl & 1;
+        } else {
+            // ---- stage 1, fp32 only.  Every pair whose exact delta can be the argmin has a filter
+            // value <= m + 2 eps and sits in a candidate macro step.  Re-evaluate those steps pair by
+            // pair (lanes 0..31) in fp32: if exactly ONE pair of the whole tour is inside the window it
+            // IS the reference's argmin, and if its value is below -1e-6 by more than eps the move is
+            // certain without any exact arithmetic.  Likewise a window that lies above -1e-6 + eps
+            // proves convergence.  Anything else falls through to the exact stage.
+            const float thr_scale = (float)(1.0e-6 * ctl->sc);
+            const float eps = 0.625f * g.eps2;                  // eps2 = 2 eps; 25 % extra margin
+            float fd = INFINITY;
+            unsigned fidx = 0xffffffffu;
+            bool multi = false;
+            if (!amb) {
+                unsigned long long cm = cmask0;
+                while (cm) {
+                    const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)cm) - 1);
+                    cm &= cm - 1;
+                    const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)chunk, src);
+                    float d;
+                    unsigned di;
+                    filter_chunk_pair<Q>(v, g, id, lane, d, di);
+                    if (d <= thr) {
+                        multi = multi || (fidx != 0xffffffffu && fidx != di);
+                        if (d < fd || (d == fd && di < fidx)) { fd = d; fidx = di; }
+                    }
+                }
+                if (tid == 0) {     // the pair (0, n-1): cyclically adjacent, not on any walked diagonal
+                    const int n = g.n;
+                    const int s0 = slot<Q>(0), s1 = slot<Q>(1), sn1 = slot<Q>(n - 1), sn = slot<Q>(n);
+                    const float d0 = dist32(v.Xq[s0].x, v.Yq[s0].x, v.Xq[sn1].x, v.Yq[sn1].x);
+                    const float d1 = dist32(v.Xq[s1].x, v.Yq[s1].x, v.Xq[sn].x, v.Yq[sn].x);
+                    const float d = ((d0 + d1) - v.Eq[sn1].x) - v.Eq[s0].x;
+                    const unsigned di = (unsigned)(n - 1);
+                    if (d <= thr) {
+                        multi = multi || (fidx != 0xffffffffu && fidx != di);
+                        if (d < fd || (d == fd && di < fidx)) { fd = d; fidx = di; }
+                    }
                 }
             }
-            if (tid == 0) {     // the pair (0, n-1): cyclically adjacent, not on any walked diagonal
-                const int n = g.n;
-                const int s0 = slot<Q>(0), s1 = slot<Q>(1), sn1 = slot<Q>(n - 1), sn = slot<Q>(n);
-                const float d0 = dist32(v.Xq[s0].x, v.Yq[s0].x, v.Xq[sn1].x, v.Yq[sn1].x);
-                const float d1 = dist32(v.Xq[s1].x, v.Yq[s1].x, v.Xq[sn].x, v.Yq[sn].x);
-                const float d = ((d0 + d1) - v.Eq[sn1].x) - v.Eq[s0].x;
-                const unsigned di = (unsigned)(n - 1);
-                if (d <= thr) {
-                    multi = multi || (fidx != 0xffffffffu && fidx != di);
-                    if (d < fd || (d == fd && di < fidx)) { fd = d; fidx = di; }
+            double wd = (double)fd;
+            unsigned widx = fidx;
+            wave_best(wd, widx);
+            const bool wother = __ballot(multi || (fidx != 0xffffffffu && fidx != widx)) != 0ull;
+            if (lane == 0) {
+                ctl->pE[wv] = wd;
+                ctl->pIdx[wv] = widx;
+                ctl->pAmb[wv] = amb | (wother ? 2 : 0);
+            }
+            __syncthreads();
+            double bd = ctl->pE[0];
+            unsigned bi = ctl->pIdx[0];
+            int fl = ctl->pAmb[0];
+            bool unique = true;
+            for (int w = 1; w < nw; ++w) {
+                const double od = ctl->pE[w];
+                const unsigned oi = ctl->pIdx[w];
+                fl |= ctl->pAmb[w];
+                if (oi != 0xffffffffu && bi != 0xffffffffu && oi != bi) unique = false;
+                if (better(od, oi, bd, bi)) { bd = od; bi = oi; }
+            }
+            amb = fl & 1;
+            unique = unique && !(fl & 2) && bi != 0xffffffffu;
+            if (!amb) {
+                if (unique && (float)bd < -thr_scale - eps) {           // certain improving move
+                    e = ((double)(float)bd + (double)eps) / ctl->sc;     // an upper bound, < -1e-6
+                    idx = bi;
+                    if (pf.on) pf.select += clock64() - t0;
+                    return;
                 }
-            }
-        }
-        double wd = (double)fd;
-        unsigned widx = fidx;
-        wave_best(wd, widx);
-        const bool wother = __ballot(multi || (fidx != 0xffffffffu && fidx != widx)) != 0ull;
-        if (lane == 0) {
-            ctl->pE[wv] = wd;
-            ctl->pIdx[wv] = widx;
-            ctl->pAmb[wv] = amb | (wother ? 2 : 0);
-        }
-        __syncthreads();
-        double bd = ctl->pE[0];
-        unsigned bi = ctl->pIdx[0];
-        int fl = ctl->pAmb[0];
-        bool unique = true;
-        for (int w = 1; w < nw; ++w) {
-            const double od = ctl->pE[w];
-            const unsigned oi = ctl->pIdx[w];
-            fl |= ctl->pAmb[w];
-            if (oi != 0xffffffffu && bi != 0xffffffffu && oi != bi) unique = false;
-            if (better(od, oi, bd, bi)) { bd = od; bi = oi; }
-        }
-        amb = fl & 1;
-        unique = unique && !(fl & 2) && bi != 0xffffffffu;
-        if (!amb) {
-            if (unique && (float)bd < -thr_scale - eps) {           // certain improving move
-                e = ((double)(float)bd + (double)eps) / ctl->sc;     // an upper bound, < -1e-6
-                idx = bi;
-                if (pf.on) pf.select += clock64() - t0;
-                return;
-            }
-            if (!need_exact_sign && m > -thr_scale + eps && (bi == 0xffffffffu || (float)bd > -thr_scale + eps)) {
-                e = 0.0;                                            // proven: no delta below -1e-6
-                idx = kNoMove;
-                if (pf.on) pf.select += clock64() - t0;
-                return;
+                if (!need_exact_sign && m > -thr_scale + eps && (bi == 0xffffffffu || (float)bd > -thr_scale + eps)) {
+                    e = 0.0;                                            // proven: no delta below -1e-6
+                    idx = kNoMove;
+                    if (pf.on) pf.select += clock64() - t0;
+                    return;
+                }
             }
         }
         __syncthreads();        // partials are rewritten below
@@ -710,15 +730,104 @@ __device__ void apply_move(const View<T>& v, const Geo& g, int tid, unsigned idx
 }
 
 // ------------------------------------------------------------------------------------------
+// cluster barrier + best-move exchange (several workgroups per tour, both cluster kernels)
+// ------------------------------------------------------------------------------------------
+constexpr unsigned kSpinLimit = 1u << 26;       // bounded wait (about 10 s): never hang the GPU
+constexpr int kSlotDw = 4;                      // delta lo, delta hi, index, flags
+
+// publish this workgroup's (e, idx), wait for the cluster, reduce all slots.  Returns false on
+// abort (a workgroup of the cluster is missing: spin limit hit).
+__device__ bool cluster_exchange(Ctl* ctl, unsigned* cs, int CS, int wc, unsigned epoch, int tid,
+                                 int nt, unsigned flags_in, double& e, unsigned& idx,
+                                 unsigned& flags_out)
+{
+    if (tid == 0) {
+        unsigned* slot = cs + 16 + ((epoch & 1u) * (unsigned)CS + (unsigned)wc) * kSlotDw;
+        __hip_atomic_store(slot + 0, (unsigned)__double2loint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 1, (unsigned)__double2hiint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 2, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 3, flags_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(cs, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned want = (unsigned)CS * (epoch + 1u);
+        unsigned spins = 0;
+        bool ok = true;
+        while (__hip_atomic_load(cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit ||
+                __hip_atomic_load(cs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(cs + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        ctl->ambiguous = ok ? 0 : 1;        // reused as the abort flag
+    }
+    __syncthreads();
+    const bool ok = ctl->ambiguous == 0;
+    // slot w is read by thread w (agent-scope loads: they bypass this CU's L1), then reduced
+    e = 0.0;
+    idx = kNoMove;
+    unsigned fl = 0;
+    if (ok && tid < CS) {
+        const unsigned* sl = cs + 16 + ((epoch & 1u) * (unsigned)CS + (unsigned)tid) * kSlotDw;
+        const unsigned lo = __hip_atomic_load(sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned hi = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        idx = __hip_atomic_load(sl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fl = __hip_atomic_load(sl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        e = __hiloint2double((int)hi, (int)lo);
+    }
+    wave_best(e, idx);
+    const int anyfl = __ballot(fl != 0u) != 0ull;
+    const int nw = nt >> 6, wv = tid >> 6;
+    if ((tid & 63) == 0) { ctl->pE[wv] = e; ctl->pIdx[wv] = idx; ctl->pAmb[wv] = anyfl; }
+    __syncthreads();
+    e = ctl->pE[0];
+    idx = ctl->pIdx[0];
+    int f = ctl->pAmb[0];
+    const int nwu = (CS + 63) >> 6 < nw ? (CS + 63) >> 6 : nw;      // waves that held slots
+    for (int w = 1; w < nwu; ++w) {
+        const double oe = ctl->pE[w];
+        const unsigned oi = ctl->pIdx[w];
+        f |= ctl->pAmb[w];
+        if (better(oe, oi, e, idx)) { e = oe; idx = oi; }
+    }
+    flags_out = f ? 1u : 0u;
+    __syncthreads();
+    return ok;
+}
+
+constexpr unsigned kFlagStop = 1u;      // published by workgroup 0: wall-clock limit reached
+
+// ------------------------------------------------------------------------------------------
 // the persistent kernel
 // ------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-template <typename T, int Q>
+// CL = several workgroups per tour ("full-window cluster", N up to the fast path's LDS limit): every
+// workgroup of a cluster holds the whole tour and the whole filter window and applies every reversal,
+// but sweeps only the lane groups gp = wc (mod CS) -- interleaved, so all workgroups see the same mix
+// of short and long diagonals and the same share of the tiles a reversal touches.  Per iteration each
+// finds the exact best move of its tiles, the cluster meets at cluster_exchange and everybody applies
+// the winner.  Clusters take tours statically (cluster, cluster + num_clusters, ...); the host
+// launches at most one workgroup per CU so that a cluster is co-resident.  Independent termination only.
+template <typename T, int Q, bool CL>
 __global__ void __launch_bounds__(1024) k_two_opt(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Geo g = p.g;
+    Geo g = p.g;
+    int64_t tk_next = 0;
+    unsigned* cs = nullptr;
+    unsigned epoch = 0;                         // barriers passed by this cluster so far
+    if constexpr (CL) {
+        g.wc = (int)(blockIdx.x % (unsigned)g.CS);
+        tk_next = blockIdx.x / (unsigned)g.CS;
+        cs = p.csync + (size_t)tk_next * (size_t)p.cstride;
+    } else {                                    // compile-time constants for the one-workgroup kernel
+        g.CS = 1;
+        g.wc = 0;
+        g.GPl = g.GP;
+    }
     const int n = g.n, tid = threadIdx.x, nt = g.nt;
     View<T> v;
     v.ctl = reinterpret_cast<Ctl*>(smem);
@@ -734,7 +843,7 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
     v.Mc = nullptr;
     v.list = nullptr;
     if (g.inc) {
-        const size_t tiles = (size_t)g.GP * g.NS * (g.MS >> 1);
+        const size_t tiles = (size_t)g.GPl * g.NS * (g.MS >> 1);
         v.Mc = reinterpret_cast<float*>(smem + off);
         off += align16(sizeof(float) * tiles);
         v.list = reinterpret_cast<uint16_t*>(smem + off);
@@ -742,15 +851,27 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
     }
     T* xl = reinterpret_cast<T*>(smem + off);
     Ctl* ctl = v.ctl;
-    Unit un{-1, 0};
+    Unit un{-1, 0, 0};
     if constexpr (Q != 0) {
-        if (tid < g.GP * g.NS) { un.gp = tid % g.GP; un.rq0 = (tid / g.GP) * (g.MS >> 1); }
+        if (tid < g.GPl * g.NS) {
+            un.gpl = tid % g.GPl;
+            un.rq0 = (tid / g.GPl) * (g.MS >> 1);
+            const int gp = CL ? g.wc + g.CS * un.gpl : un.gpl;
+            if (!CL || gp < g.GP) un.gp = gp;
+        }
     }
     for (;;) {
         __syncthreads();
-        if (tid == 0) { ctl->tour_id = (int)atomicAdd(p.queue, 1u); ctl->nlist = 0; }
-        __syncthreads();
-        const int64_t tk = ctl->tour_id;
+        int64_t tk;
+        if constexpr (CL) {
+            if (tid == 0) ctl->nlist = 0;
+            tk = tk_next;
+            tk_next += p.num_clusters;
+        } else {
+            if (tid == 0) { ctl->tour_id = (int)atomicAdd(p.queue, 1u); ctl->nlist = 0; }
+            __syncthreads();
+            tk = ctl->tour_id;
+        }
         if (tk >= p.num_tours) break;          // uniform exit: every wave leaves here
 
         const int64_t grp = tk / p.group_size;
@@ -820,7 +941,7 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
         const int flags = ctl->flags;
         v.X = g.xlds ? xl : X;
         if (flags != 0) {                       // invalid input: tour untouched (uniform branch)
-            if (tid == 0) {
+            if (tid == 0 && g.wc == 0) {
                 if (p.status) p.status[tk] = flags;
                 if (p.mode == kModeIndep) p.iters[tk] = 0;
             }
@@ -856,7 +977,7 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
                 for (int k = 0; k < p.dbg_sweeps; ++k) {
                     float a1, a2;
                     unsigned chunk;
-                    filter_sweep<Q>(v.Xq, v.Yq, v.Eq, v.Mc, g, tid, a1, a2, chunk);
+                    filter_sweep<Q, CL>(v.Xq, v.Yq, v.Eq, v.Mc, g, tid, a1, a2, chunk);
                     acc += a1 + a2 + (float)chunk;
                     asm volatile("" ::: "memory");
                 }
@@ -879,8 +1000,19 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
         for (;;) {
             const bool check_only = forced && it >= target;
             if (check_only && target >= p.max_iter) break;
-            find_best<T, Q>(v, g, tid, un, forced, last, e, idx, pf);
+            find_best<T, Q, CL>(v, g, tid, un, forced, last, e, idx, pf);
             ++sweeps;
+            unsigned xfl = 0;
+            if constexpr (CL) {
+                unsigned myflags = 0;
+                if (g.wc == 0 && p.time_limit_ticks && wall_clock64() - t_start > p.time_limit_ticks)
+                    myflags |= kFlagStop;
+                if (!cluster_exchange(ctl, cs, g.CS, g.wc, epoch, tid, nt, myflags, e, idx, xfl)) {
+                    st = TSP2OPT_ST_INTERNAL;
+                    break;
+                }
+                ++epoch;
+            }
             const bool active = e < -1.0e-6;
             bool stop_after = false;
             if (!forced) {
@@ -906,7 +1038,8 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
             ++it;
             if (!forced) {
                 if (it >= p.max_iter) { st |= TSP2OPT_ST_CAPPED; break; }   // two_opt.py:47
-                if (p.time_limit_ticks && wall_clock64() - t_start > p.time_limit_ticks) {
+                if (CL ? (xfl & kFlagStop) != 0u
+                       : (p.time_limit_ticks && wall_clock64() - t_start > p.time_limit_ticks)) {
                     st |= TSP2OPT_ST_TIME;                                  // plugin two_opt.py:63-65
                     break;
                 }
@@ -917,6 +1050,11 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
 
         // ---- write back ------------------------------------------------------------------------
         __builtin_amdgcn_s_setprio(0);
+        if (CL && st == TSP2OPT_ST_INTERNAL) {  // cluster broken (a workgroup is missing): tours untouched
+            if (g.wc == 0 && tid == 0 && p.status) p.status[tk] = st;
+            return;
+        }
+        if (CL && g.wc != 0) continue;          // every workgroup holds the same tour; the first writes it
         for (int k = tid; k <= n; k += nt) gt[k] = (int64_t)v.tour[k];
         if (tid == 0) {
             p.iters[tk] = it;
@@ -979,9 +1117,6 @@ struct CParams {
     unsigned long long* stamps;     // optional phase timers (tsp2opt_debug_phase_cycles)
     CGeo g;
 };
-
-constexpr unsigned kSpinLimit = 1u << 26;       // bounded wait (about 10 s): never hang the GPU
-constexpr int kSlotDw = 4;                      // delta lo, delta hi, index, flags
 
 template <typename T>
 struct CView {
@@ -1337,70 +1472,6 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
     }
     if (pf.on) pf.select += clock64() - t0;
 }
-
-// publish this workgroup's (e, idx), wait for the cluster, reduce all slots.  Returns false on
-// abort (a workgroup of the cluster is missing: spin limit hit).
-__device__ bool cluster_exchange(Ctl* ctl, unsigned* cs, int CS, int wc, unsigned epoch, int tid,
-                                 int nt, unsigned flags_in, double& e, unsigned& idx,
-                                 unsigned& flags_out)
-{
-    if (tid == 0) {
-        unsigned* slot = cs + 16 + ((epoch & 1u) * (unsigned)CS + (unsigned)wc) * kSlotDw;
-        __hip_atomic_store(slot + 0, (unsigned)__double2loint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slot + 1, (unsigned)__double2hiint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slot + 2, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slot + 3, flags_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(cs, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned want = (unsigned)CS * (epoch + 1u);
-        unsigned spins = 0;
-        bool ok = true;
-        while (__hip_atomic_load(cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinLimit ||
-                __hip_atomic_load(cs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                __hip_atomic_store(cs + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = false;
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        ctl->ambiguous = ok ? 0 : 1;        // reused as the abort flag
-    }
-    __syncthreads();
-    const bool ok = ctl->ambiguous == 0;
-    // slot w is read by thread w (agent-scope loads: they bypass this CU's L1), then reduced
-    e = 0.0;
-    idx = kNoMove;
-    unsigned fl = 0;
-    if (ok && tid < CS) {
-        const unsigned* sl = cs + 16 + ((epoch & 1u) * (unsigned)CS + (unsigned)tid) * kSlotDw;
-        const unsigned lo = __hip_atomic_load(sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned hi = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        idx = __hip_atomic_load(sl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fl = __hip_atomic_load(sl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        e = __hiloint2double((int)hi, (int)lo);
-    }
-    wave_best(e, idx);
-    const int anyfl = __ballot(fl != 0u) != 0ull;
-    const int nw = nt >> 6, wv = tid >> 6;
-    if ((tid & 63) == 0) { ctl->pE[wv] = e; ctl->pIdx[wv] = idx; ctl->pAmb[wv] = anyfl; }
-    __syncthreads();
-    e = ctl->pE[0];
-    idx = ctl->pIdx[0];
-    int f = ctl->pAmb[0];
-    const int nwu = (CS + 63) >> 6 < nw ? (CS + 63) >> 6 : nw;      // waves that held slots
-    for (int w = 1; w < nwu; ++w) {
-        const double oe = ctl->pE[w];
-        const unsigned oi = ctl->pIdx[w];
-        f |= ctl->pAmb[w];
-        if (better(oe, oi, e, idx)) { e = oe; idx = oi; }
-    }
-    flags_out = f ? 1u : 0u;
-    __syncthreads();
-    return ok;
-}
-
-constexpr unsigned kFlagStop = 1u;      // published by workgroup 0: wall-clock limit reached
 
 template <typename T, int MAXNT>
 __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
@@ -1792,15 +1863,20 @@ struct Plan {
 };
 
 constexpr size_t kLdsMax = 160 * 1024;
+constexpr size_t kCsyncBytes = 64 * 1024;   // cluster barrier words + slots (<= 256 workgroups)
 const int kQClasses[] = {16, 32, 64, 128, 256, 512};
 
 int g_force_nt = 0;         // diagnostic: threads per workgroup of the single-workgroup plan
 int g_lcap16 = 8;           // diagnostic: changed-group list capacity of the cluster kernel, in 1/16 of the groups
+int g_inc_min_tiles = 2;    // tile cache only when a lane owns at least this many tiles (measured: TSP-50 / TSP-100)
 
-Plan make_plan(int n, int dtype)
+// cs > 1: geometry of one workgroup of a full-window cluster of cs workgroups (lane groups interleaved)
+Plan make_plan(int n, int dtype, int cs = 1)
 {
     Plan pl{};
     Geo& g = pl.g;
+    g.CS = cs;
+    g.wc = 0;
     const size_t tsz = dtype == TSP2OPT_DTYPE_F64 ? 8 : 4;
     g.n = n;
     g.eps2 = dtype == TSP2OPT_DTYPE_F64 ? 2.0f * 0x1p-16f : 2.0f * 0x1p-15f;
@@ -1816,10 +1892,12 @@ Plan make_plan(int n, int dtype)
         const int dn = n / 2 - 1;                       // cyclic diagonals 2..n/2
         const int GP = (dn + 7) / 8;                    // lane groups of 8 adjacent diagonals
         const int G = 2 * GP;
+        const int GPl = (GP + cs - 1) / cs;             // lane groups per workgroup
+        g.GPl = GPl;
         // every walked diagonal d = 2..8GP+1 must be a valid pair distance: d <= n-2
         if (GP >= 1 && 8 * GP + 1 <= n - 2) {
             const int R = (n + 3) / 4;                  // macro-step rows needed
-            int NS = nt / GP;
+            int NS = nt / GPl;
             if (NS < 1) NS = 1;
             if (NS > (R + 1) / 2) NS = (R + 1) / 2;
             int MS = (R + NS - 1) / NS;
@@ -1839,9 +1917,9 @@ Plan make_plan(int n, int dtype)
             if (g.qclass) {
                 // minimum cache (4 B per tile) + changed-tile list (2 B per entry, half the tiles: measured,
                 // beyond that a plain sweep is cheaper than recomputing tile by tile)
-                const size_t tiles = (size_t)GP * NS * (MS / 2);
+                const size_t tiles = (size_t)GPl * NS * (MS / 2);
                 const size_t need = align16(4 * tiles) + align16(2 * (tiles / 2 + 1));
-                if ((size_t)NS * (MS / 2) <= 255 && GP <= 255 && MS / 2 <= 64 && GP * NS <= nt &&
+                if (MS / 2 >= g_inc_min_tiles && (size_t)NS * (MS / 2) <= 255 && GPl <= 255 && MS / 2 <= 64 && GPl * NS <= nt &&
                     base + (size_t)g.qclass * 192 + need <= kLdsMax) {
                     g.inc = 1;
                     g.lcap = (int)(tiles / 2 + 1);
@@ -1854,7 +1932,7 @@ Plan make_plan(int n, int dtype)
     // cache the exact coordinates in LDS when that still leaves >= 4 workgroups per CU (or fits at all
     // for single-workgroup-per-CU sizes)
     g.xlds = 0;
-    if (pl.lds + xbytes <= kLdsMax && (pl.lds + xbytes <= 40 * 1024 || nt >= 512)) {
+    if (pl.lds + xbytes <= kLdsMax && (pl.lds + xbytes <= 40 * 1024 || nt >= 512 || cs > 1)) {
         g.xlds = 1;
         pl.lds += align16(xbytes);
     }
@@ -1864,7 +1942,7 @@ Plan make_plan(int n, int dtype)
 template <typename T, int Q>
 int launch_main(const Params& p, const Plan& pl, int device, hipStream_t stream, int* blocks_per_cu)
 {
-    auto kern = k_two_opt<T, Q>;
+    auto kern = k_two_opt<T, Q, false>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
     int per_cu = 0;
@@ -1879,6 +1957,37 @@ int launch_main(const Params& p, const Plan& pl, int device, hipStream_t stream,
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)pl.g.nt), pl.lds, stream, p);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// full-window cluster: `clusters` x CS workgroups, at most one per CU (co-residency)
+template <typename T, int Q>
+int launch_fw(Params p, const Plan& pl, int cus, hipStream_t stream)
+{
+    auto kern = k_two_opt<T, Q, true>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    const int CS = pl.g.CS;
+    int clusters = cus / CS;
+    if (clusters > p.num_tours) clusters = (int)p.num_tours;
+    if (clusters < 1) return fail(TSP2OPT_E_UNSUPPORTED, "cluster does not fit the device");
+    p.num_clusters = clusters;
+    p.cstride = ((16 + 2 * CS * kSlotDw) + 63) & ~63;
+    if ((size_t)clusters * (size_t)p.cstride * 4 > kCsyncBytes)
+        return fail(TSP2OPT_E_UNSUPPORTED, "internal: cluster sync area too small");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(clusters * CS)), dim3((unsigned)pl.g.nt), pl.lds, stream, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+int dispatch_fw(const Params& p, const Plan& pl, int cus, hipStream_t stream)
+{
+    switch (pl.g.qclass) {
+    case 128: return launch_fw<T, 128>(p, pl, cus, stream);
+    case 256: return launch_fw<T, 256>(p, pl, cus, stream);
+    case 512: return launch_fw<T, 512>(p, pl, cus, stream);
+    }
+    return fail(TSP2OPT_E_ARG, "internal: no full-window cluster kernel for this filter class");
 }
 
 template <typename T>
@@ -1898,7 +2007,6 @@ int dispatch_main(const Params& p, const Plan& pl, int device, hipStream_t strea
 
 // workspace layout: [0,256) control words (queue head at 0); then target[groups], flag[groups],
 // iters[num_tours], work[num_tours], status[num_tours] (each 256-byte aligned)
-constexpr size_t kCsyncBytes = 64 * 1024;   // cluster barrier words + slots (<= 256 workgroups)
 struct WsLayout {
     size_t off_target, off_flag, off_iters, off_work, off_status, off_csync, total;
 };
@@ -2021,17 +2129,43 @@ int launch_cluster(CParams p, const CPlan& cp, int cus, hipStream_t stream)
 
 int g_cluster_mode = -1;    // -1 auto, 0 never, >= 2 force that many workgroups per tour (tests)
 
-// few tours (or N beyond one workgroup's LDS): several workgroups per tour; !ok = one workgroup per tour
-CPlan choose_cluster(int n, int dtype, int64_t num_tours, int cus, const Plan& pl)
+int g_cluster_variant = 0;  // 0 auto, 1 band kernel only (k_two_opt_cluster), 2 full-window kernel only
+
+// Several workgroups per tour?  kind 0: no (one workgroup per tour), 1: band cluster
+// (k_two_opt_cluster, any N), 2: full-window cluster (k_two_opt<.., true>, N within the fast path).
+struct ClusterChoice {
+    int kind;
+    CPlan band;
+    Plan fw;
+};
+
+ClusterChoice choose_cluster(int n, int dtype, int64_t num_tours, int cus, const Plan& pl)
 {
+    ClusterChoice c{};
+    c.kind = 0;
     int cap = (int)std::min<int64_t>(64, cus / std::max<int64_t>(1, num_tours));
+    const bool forced = g_cluster_mode >= 2;
+    if (forced) cap = std::min(g_cluster_mode, cus);
+    // full-window cluster: needs the fast path (and one of the instantiated filter classes) with the
+    // whole window in LDS; at least 4 lane groups per workgroup
+    if (g_cluster_variant != 1 && cap >= 2 && pl.g.qclass != 0 && (forced || n >= 700)) {
+        const int cs = std::min(cap, std::max(1, pl.g.GP / 4));
+        if (cs >= 2) {
+            const Plan fw = make_plan(n, dtype, cs);
+            if (fw.g.qclass >= 128) { c.kind = 2; c.fw = fw; return c; }
+        }
+    }
+    if (g_cluster_variant == 2) return c;
     bool smallest = false;
-    if (g_cluster_mode >= 2) cap = std::min(g_cluster_mode, cus);
-    else if (pl.g.qclass == 0 && cap < 2) { cap = 64; smallest = true; }   // tiling for LDS only
-    else if (pl.g.qclass != 0 && (n < 700 || cap < 3)) cap = 0;
-    // (small tours are not worth a barrier; with two workgroups per tour the one-workgroup kernel with
-    //  its finer incremental sweeps is faster even on half the CUs: TSP-1000 x 128, 26.9 vs 35 ms)
-    return make_cluster_plan(n, dtype, cap, smallest);
+    if (!forced) {
+        if (pl.g.qclass == 0 && cap < 2) { cap = 64; smallest = true; }        // tiling for LDS only
+        else if (pl.g.qclass != 0 && (n < 700 || cap < 3)) cap = 0;
+        // (small tours are not worth a barrier; with two band workgroups per tour the one-workgroup
+        //  kernel with its finer incremental sweeps is faster even on half the CUs)
+    }
+    c.band = make_cluster_plan(n, dtype, cap, smallest);
+    if (c.band.ok) c.kind = 1;
+    return c;
 }
 
 template <typename T>
@@ -2076,26 +2210,33 @@ int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* swe
     int rc = prof_record(device, 0, stream);
     if (rc) return rc;
     // few tours (or N beyond one workgroup's LDS): several workgroups per tour
-    CPlan cp{};
-    cp.ok = false;
+    ClusterChoice cc{};
+    cc.kind = 0;
     if (group_size == 1 && g_cluster_mode != 0 && g_dbg_sweeps == 0) {
         int cus = 0;
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-        cp = choose_cluster(n, dtype, num_tours, cus, pl);
-        if (cp.ok) {
+        cc = choose_cluster(n, dtype, num_tours, cus, pl);
+        if (cc.kind != 0) HIP_TRY(hipMemsetAsync(w8 + wl.off_csync, 0, kCsyncBytes, stream));
+        if (cc.kind == 1) {
+            const CPlan& cp = cc.band;
             CParams c{};
             c.points = points; c.tours = tours; c.iters = p.iters; c.work_sweeps = p.work_sweeps;
             c.status = p.status; c.csync = reinterpret_cast<unsigned*>(w8 + wl.off_csync);
             c.num_tours = num_tours; c.tpi = tpi; c.max_iter = max_iter;
             c.time_limit_ticks = p.time_limit_ticks; c.g = cp.g;
             c.stamps = p.stamps;
-            HIP_TRY(hipMemsetAsync(w8 + wl.off_csync, 0, kCsyncBytes, stream));
             rc = cp.g.nt <= 512 ? launch_cluster<T, 512>(c, cp, cus, stream)
                                 : launch_cluster<T, 768>(c, cp, cus, stream);
             if (rc) return rc;
+        } else if (cc.kind == 2) {
+            Params pc = p;
+            pc.g = cc.fw.g;
+            pc.csync = reinterpret_cast<unsigned*>(w8 + wl.off_csync);
+            rc = dispatch_fw<T>(pc, cc.fw, cus, stream);
+            if (rc) return rc;
         }
     }
-    if (!cp.ok) {
+    if (cc.kind == 0) {
         rc = dispatch_main<T>(p, pl, device, stream);
         if (rc) return rc;
     }
@@ -2355,6 +2496,8 @@ extern "C" int tsp2opt_debug_tune(int32_t what, int32_t value)
 {
     if (what == 0) g_force_nt = value;
     else if (what == 1) g_lcap16 = value < 1 ? 1 : value > 16 ? 16 : value;
+    else if (what == 2) g_inc_min_tiles = value;
+    else if (what == 3) g_cluster_variant = value;
     else return fail(TSP2OPT_E_ARG, "unknown tuning knob");
     return 0;
 }
@@ -2364,12 +2507,20 @@ extern "C" int tsp2opt_cluster_plan(int32_t n, int32_t dtype, int64_t num_tours,
     if (n < 1 || n > TSP2OPT_MAX_N || num_tours < 1 || cus < 1 || !out12) return fail(TSP2OPT_E_ARG, "bad argument");
     if (dtype != TSP2OPT_DTYPE_F32 && dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
     const Plan pl = make_plan(n, dtype);
-    const CPlan cp = g_cluster_mode == 0 ? CPlan{} : choose_cluster(n, dtype, num_tours, cus, pl);
     for (int k = 0; k < 12; ++k) out12[k] = 0;
-    if (!cp.ok) return 0;
-    out12[0] = cp.g.CS; out12[1] = cp.g.CR; out12[2] = cp.g.CD; out12[3] = cp.g.nt;
-    out12[4] = cp.g.GPw; out12[5] = cp.g.NSw; out12[6] = cp.g.MS; out12[7] = (int32_t)cp.lds;
-    out12[8] = cp.g.inc; out12[9] = cp.g.K; out12[10] = cp.g.NG; out12[11] = cp.g.xlds;
+    if (g_cluster_mode == 0) return 0;
+    const ClusterChoice cc = choose_cluster(n, dtype, num_tours, cus, pl);
+    if (cc.kind == 1) {
+        const CPlan& cp = cc.band;
+        out12[0] = cp.g.CS; out12[1] = cp.g.CR; out12[2] = cp.g.CD; out12[3] = cp.g.nt;
+        out12[4] = cp.g.GPw; out12[5] = cp.g.NSw; out12[6] = cp.g.MS; out12[7] = (int32_t)cp.lds;
+        out12[8] = cp.g.inc; out12[9] = cp.g.K; out12[10] = cp.g.NG; out12[11] = cp.g.xlds;
+    } else if (cc.kind == 2) {
+        const Geo& g = cc.fw.g;
+        out12[0] = g.CS; out12[1] = 0; out12[2] = g.CS; out12[3] = g.nt;
+        out12[4] = g.GPl; out12[5] = g.NS; out12[6] = g.MS; out12[7] = (int32_t)cc.fw.lds;
+        out12[8] = g.inc; out12[9] = 2; out12[10] = g.MS / 2; out12[11] = g.xlds;
+    }
     return 0;
 }
 

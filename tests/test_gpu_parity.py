@@ -139,42 +139,58 @@ def test_gpu_time_limit_stops_early(amd):
     assert (np.sort(out[:, :-1], axis=1) == np.arange(1000)).all()
 
 
-# ---- several workgroups per tour (cluster kernel) ------------------------------------------------
+# ---- several workgroups per tour (cluster kernels) -----------------------------------------------
+# variant 0: automatic (full-window cluster when the fast path holds the whole window, else bands),
+# 1: band kernel (k_two_opt_cluster), 2: full-window kernel (k_two_opt<.., true>) or nothing
 CLUSTER_CASES = [
-    # n, tours, dtype, cap, forced workgroups per tour (0 = automatic choice)
-    (64, 3, np.float64, 5000, 2), (100, 5, np.float64, 5000, 4), (200, 2, np.float32, 5000, 8),
-    (500, 3, np.float64, 5000, 16), (500, 2, np.float64, 5000, 2), (777, 2, np.float64, 5000, 0),
-    (1000, 4, np.float64, 5000, 0), (1000, 1, np.float32, 5000, 0), (1500, 1, np.float64, 300, 32),
-    (3000, 2, np.float64, 60, 0), (5000, 1, np.float64, 40, 0),
+    # n, tours, dtype, cap, forced workgroups per tour (0 = automatic choice), variant
+    (64, 3, np.float64, 5000, 2, 0), (100, 5, np.float64, 5000, 4, 0), (200, 2, np.float32, 5000, 8, 0),
+    (500, 3, np.float64, 5000, 16, 1), (500, 2, np.float64, 5000, 2, 1), (777, 2, np.float64, 5000, 0, 1),
+    (1000, 4, np.float64, 5000, 0, 1), (1000, 1, np.float32, 5000, 0, 1), (1500, 1, np.float64, 300, 32, 1),
+    (3000, 2, np.float64, 60, 0, 0), (5000, 1, np.float64, 40, 0, 0),
     # coarse cache entries (K > 1 macro steps per entry: LDS-limited geometries)
-    (2000, 2, np.float64, 150, 2), (2500, 1, np.float32, 120, 3), (6000, 1, np.float64, 30, 8),
+    (2000, 2, np.float64, 150, 2, 1), (2500, 1, np.float32, 120, 3, 1), (6000, 1, np.float64, 30, 8, 0),
+    # full-window cluster: lane groups interleaved over the workgroups
+    (400, 3, np.float64, 5000, 4, 2), (500, 3, np.float64, 5000, 16, 2), (500, 2, np.float32, 5000, 3, 2),
+    (777, 2, np.float64, 5000, 0, 0), (1000, 4, np.float64, 5000, 0, 0), (1000, 1, np.float32, 5000, 0, 0),
+    (1000, 9, np.float64, 5000, 2, 2), (1500, 1, np.float64, 300, 32, 2), (2000, 2, np.float64, 150, 5, 2),
+    (2500, 1, np.float32, 120, 0, 0),
 ]
 
 
-@pytest.mark.parametrize("n,tours_n,dtype,cap,force", CLUSTER_CASES)
-def test_gpu_cluster_kernel_matches_oracle(amd, oracle, n, tours_n, dtype, cap, force):
+@pytest.mark.parametrize("n,tours_n,dtype,cap,force,variant", CLUSTER_CASES)
+def test_gpu_cluster_kernel_matches_oracle(amd, oracle, n, tours_n, dtype, cap, force, variant):
     from ml4tspbench_amd import _lib
+    L = _lib.lib()
     rng = np.random.default_rng(7000 + n + force)
     pts, tours = _random_batch(rng, tours_n, 1, n, dtype)
     ref_out, ref_it, ref_sw = oracle.solve(pts, tours, max_iterations=cap, threads=8)
-    _lib.lib().tsp2opt_debug_cluster_mode(force if force else -1)
+    L.tsp2opt_debug_cluster_mode(force if force else -1)
+    L.tsp2opt_debug_tune(3, variant)
     try:
+        plan = _lib.cluster_plan(n, _lib.DTYPE_F64 if dtype == np.float64 else _lib.DTYPE_F32, tours_n, 256)
+        assert plan["workgroups_per_tour"] >= 2, plan          # the case really runs a cluster kernel
+        if variant:
+            assert (plan["row_bands"] == 0) == (variant == 2), plan
         out, iters, sweeps, lengths, status = _run(amd, pts, tours, 1, 1, cap)
     finally:
-        _lib.lib().tsp2opt_debug_cluster_mode(-1)
+        L.tsp2opt_debug_cluster_mode(-1)
+        L.tsp2opt_debug_tune(3, 0)
     assert (status & (15 | 64)).max(initial=0) == 0
     assert np.array_equal(out, ref_out)
     assert np.array_equal(iters, ref_it)
     assert np.array_equal(sweeps, ref_sw)
 
 
-def test_gpu_cluster_kernel_goldens_and_ties(amd):
-    """Goldens through the cluster kernel, including the tie-heavy grids (exact tile sweep path)."""
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gpu_cluster_kernel_goldens_and_ties(amd, variant):
+    """Goldens through the cluster kernels, including the tie-heavy grids (exact sweep path)."""
     from ml4tspbench_amd import _lib
     names = ["g2_n100_indep_f64", "g9_grid12_indep_f64", "g9_grid8_indep_f32", "g9_n120_clustered_f64",
              "g9_n80_offset_scaled_f64", "g7_n500_indep_f32", "g4_n1000_indep_f64", "g5_n10000_cap32_f64",
              "g6_n50_cap7_f64", "g9_n40_duplicates_f64"]
     _lib.lib().tsp2opt_debug_cluster_mode(4)
+    _lib.lib().tsp2opt_debug_tune(3, variant)
     try:
         for nm in names:
             g = load_golden(f"{GOLDEN}/{nm}.npz")
@@ -185,3 +201,24 @@ def test_gpu_cluster_kernel_goldens_and_ties(amd):
             assert np.array_equal(iters, g["iterators"]), nm
     finally:
         _lib.lib().tsp2opt_debug_cluster_mode(-1)
+        _lib.lib().tsp2opt_debug_tune(3, 0)
+
+
+def test_gpu_cluster_time_limit(amd):
+    """The wall-clock limit travels through the cluster exchange (workgroup 0 decides for all)."""
+    from ml4tspbench_amd import _lib
+    rng = np.random.default_rng(66)
+    pts, tours = _random_batch(rng, 1, 1, 1200, np.float64)
+    dev = torch.device("cuda", 0)
+    for variant in (1, 2):
+        _lib.lib().tsp2opt_debug_tune(3, variant)
+        try:
+            res = amd.two_opt_device(torch.from_numpy(pts).to(dev), torch.from_numpy(tours).to(dev),
+                                     time_limit=1e-4)
+            torch.cuda.synchronize()
+        finally:
+            _lib.lib().tsp2opt_debug_tune(3, 0)
+        st = res.status.cpu().numpy()
+        assert (st & _lib.ST_TIME).all() and (res.iterations.cpu().numpy() < 800).all()
+        out = res.tours.cpu().numpy()
+        assert (np.sort(out[:, :-1], axis=1) == np.arange(1200)).all()
