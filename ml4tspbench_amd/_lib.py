@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtsp2opt_hip.so")
+# TSP2OPT_LIB: load another build of the same library (the -DTSP2OPT_FINE diagnostic variant)
+LIB_PATH = os.environ.get("TSP2OPT_LIB") or os.path.join(_HERE, "libtsp2opt_hip.so")
 
 DTYPE_F32 = 0
 DTYPE_F64 = 1

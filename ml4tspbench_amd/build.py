@@ -26,16 +26,19 @@ FLAGS = [
 ]
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, fine: bool = False) -> str:
+    """fine=True: the diagnostic variant libtsp2opt_hip_fine.so (-DTSP2OPT_FINE: sub-phase cycle marks,
+    tools/phase_breakdown.py --fine); never the library that is benchmarked or shipped."""
+    lib = LIB.replace(".so", "_fine.so") if fine else LIB
     newest = max(os.path.getmtime(f) for f in SRCS + DEPS + [HDR, __file__])
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
-        return LIB
-    cmd = [HIPCC, *FLAGS, "-o", LIB, *SRCS]
+    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= newest:
+        return lib
+    cmd = [HIPCC, *FLAGS, *(["-DTSP2OPT_FINE"] if fine else []), "-o", lib, *SRCS]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, fine="--fine" in sys.argv))

@@ -104,7 +104,20 @@ struct Prof {                         // per-thread phase timers, only live when
     unsigned long long sweep, select, apply;
     unsigned amb = 0, cands = 0;
     unsigned long long candcyc = 0;
+#ifdef TSP2OPT_FINE
+    unsigned long long tl = 0, fine[16] = {};
+#endif
 };
+
+// Diagnostic build only (-DTSP2OPT_FINE, libtsp2opt_hip_fine.so): FINE(pf, k) charges the shader-clock
+// cycles since the previous mark to slot k; the slots are summed into workspace stamps [8, 24).
+#ifdef TSP2OPT_FINE
+#define FINE_START(pf) do { if ((pf).on) (pf).tl = clock64(); } while (0)
+#define FINE(pf, k) do { if ((pf).on) { const unsigned long long t_ = clock64(); (pf).fine[k] += t_ - (pf).tl; (pf).tl = t_; } } while (0)
+#else
+#define FINE_START(pf) do { } while (0)
+#define FINE(pf, k) do { } while (0)
+#endif
 
 struct Ctl {                          // LDS control block (first bytes of dynamic LDS)
     double redd[kMaxWaves * 4];       // block reductions
@@ -400,10 +413,11 @@ struct Unit {               // the lane's own unit, fixed for the whole kernel
 // cached tile minima exactly as the full sweep would.
 template <int Q, bool CL, typename T>
 __device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, const Unit& un,
-                                      unsigned last, float& a1, float& a2, unsigned& chunk)
+                                      unsigned last, float& a1, float& a2, unsigned& chunk, Prof& pf)
 {
     Ctl* ctl = v.ctl;
     bool full = !g.inc || last == kFullSweep;
+    FINE_START(pf);
     if (!full) {
         const int MS2 = g.MS >> 1;
         const int i = (int)(last >> 16), j = (int)(last & 0xffffu);
@@ -432,6 +446,7 @@ __device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, c
                 base += (unsigned)__popcll(b);
             }
         }
+        FINE(pf, 0);                                        // marking + compaction
         __syncthreads();
         const unsigned nl = ctl->nlist;
         if (nl > (unsigned)g.lcap) {
@@ -445,6 +460,7 @@ __device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, c
             }
             __builtin_amdgcn_s_setprio(3);
         }
+        FINE(pf, 1);                                        // barrier + changed tiles
         __syncthreads();
         if (tid == 0) ctl->nlist = 0;
         if (!full) {
@@ -460,12 +476,22 @@ __device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, c
                     mc += g.GPl;
                 }
             }
+            FINE(pf, 2);                                    // barrier + reduction of the cached minima
             return;
         }
     }
     __builtin_amdgcn_s_setprio(0);
     filter_sweep<Q, CL>(v.Xq, v.Yq, v.Eq, g.inc ? v.Mc : nullptr, g, tid, a1, a2, chunk);
     __builtin_amdgcn_s_setprio(3);
+    FINE(pf, 3);                                            // full sweep
+}
+
+// window position -> tour position; window positions are below 3n (make_plan guarantees W < 3n)
+__device__ __forceinline__ int wrap3(int w, int n)
+{
+    w -= w >= n ? n : 0;
+    w -= w >= n ? n : 0;
+    return w;
 }
 
 // window positions (row, column) of pair `pr` (0..63: row 0..7, diagonal 0..7) of tile `id`
@@ -482,7 +508,7 @@ __device__ __forceinline__ void eval_chunk_pair(const View<T>& v, const Geo& g, 
 {
     int rw, cw;
     tile_pair(g, id, pr, rw, cw);
-    const int r = rw % g.n, c = cw % g.n;
+    const int r = wrap3(rw, g.n), c = wrap3(cw, g.n);
     const int i = r < c ? r : c, j = r < c ? c : r;
     e = exact_delta(v, i, j);
     idx = ((unsigned)i << 16) | (unsigned)j;
@@ -500,7 +526,7 @@ __device__ __forceinline__ void filter_chunk_pair(const View<T>& v, const Geo& g
     const float d0 = dist32(v.Xq[sr].x, v.Yq[sr].x, v.Xq[sc].x, v.Yq[sc].x);
     const float d1 = dist32(v.Xq[sr1].x, v.Yq[sr1].x, v.Xq[sc1].x, v.Yq[sc1].x);
     d = ((d0 + d1) - v.Eq[sc].x) - v.Eq[sr].x;
-    const int r = rw % g.n, c = cw % g.n;
+    const int r = wrap3(rw, g.n), c = wrap3(cw, g.n);
     const int i = r < c ? r : c, j = r < c ? c : r;
     idx = ((unsigned)i << 16) | (unsigned)j;
 }
@@ -511,9 +537,11 @@ __device__ __forceinline__ void filter_chunk_pair(const View<T>& v, const Geo& g
 // continuation); otherwise a minimum proven >= -1e-6 by the filter alone ends the search.
 // CL (several workgroups per tour): this workgroup's tiles only, always exact (the result is compared
 // with the other workgroups' results), no fp32-only shortcut.
+// `spd` (thread 0 only): cached filter value of the pair (0, n-1); its operands P[1], P[n-1], e[0],
+// e[n-1] change only when the last reversal started at position 1 or ended at position n-1.
 template <typename T, int Q, bool CL>
 __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& un, bool need_exact_sign,
-                          unsigned last, double& e, unsigned& idx, Prof& pf)
+                          unsigned last, float& spd, double& e, unsigned& idx, Prof& pf)
 {
     Ctl* ctl = v.ctl;
     unsigned long long t0 = 0;
@@ -528,7 +556,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& u
         // everything outside the sweep arithmetic is a latency chain that idles most of the
         // workgroup: it runs at high issue priority (set inside sweep()) so that the other
         // workgroups' sweeps on this SIMD do not stretch it
-        sweep<Q, CL>(v, g, tid, un, last, a1, a2, chunk);
+        sweep<Q, CL>(v, g, tid, un, last, a1, a2, chunk, pf);
         if (pf.on) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
         const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
         const float wm = wave_min(a1);
@@ -539,6 +567,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& u
         const float thr = m + g.eps2;
         const unsigned long long cmask0 = __ballot(a1 <= thr);
         int amb = __ballot(a2 <= thr) != 0ull || __popcll(cmask0) > 8;
+        FINE(pf, 4);                                        // workgroup minimum of the filter
 
         if constexpr (CL) {
             if (lane == 0) ctl->pAmb[wv] = amb;
@@ -574,10 +603,13 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& u
                 }
                 if (tid == 0) {     // the pair (0, n-1): cyclically adjacent, not on any walked diagonal
                     const int n = g.n;
-                    const int s0 = slot<Q>(0), s1 = slot<Q>(1), sn1 = slot<Q>(n - 1), sn = slot<Q>(n);
-                    const float d0 = dist32(v.Xq[s0].x, v.Yq[s0].x, v.Xq[sn1].x, v.Yq[sn1].x);
-                    const float d1 = dist32(v.Xq[s1].x, v.Yq[s1].x, v.Xq[sn].x, v.Yq[sn].x);
-                    const float d = ((d0 + d1) - v.Eq[sn1].x) - v.Eq[s0].x;
+                    if (last == kFullSweep || (last >> 16) == 0u || (last & 0xffffu) == (unsigned)(n - 1)) {
+                        const int s0 = slot<Q>(0), s1 = slot<Q>(1), sn1 = slot<Q>(n - 1), sn = slot<Q>(n);
+                        const float d0 = dist32(v.Xq[s0].x, v.Yq[s0].x, v.Xq[sn1].x, v.Yq[sn1].x);
+                        const float d1 = dist32(v.Xq[s1].x, v.Yq[s1].x, v.Xq[sn].x, v.Yq[sn].x);
+                        spd = ((d0 + d1) - v.Eq[sn1].x) - v.Eq[s0].x;
+                    }
+                    const float d = spd;
                     const unsigned di = (unsigned)(n - 1);
                     if (d <= thr) {
                         multi = multi || (fidx != 0xffffffffu && fidx != di);
@@ -585,9 +617,13 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& u
                     }
                 }
             }
-            double wd = (double)fd;
-            unsigned widx = fidx;
-            wave_best(wd, widx);
+            FINE(pf, 5);                                    // fp32 re-evaluation of the candidate tiles
+            // wave result: the minimum value and, when every in-window pair of the wave is the same
+            // pair, that pair (otherwise the index is not used: `wother` sends the search to stage 2)
+            const unsigned long long hm = __ballot(fidx != 0xffffffffu);
+            double wd = (double)wave_min(fd);
+            unsigned widx = 0xffffffffu;
+            if (hm) widx = (unsigned)__builtin_amdgcn_readlane((int)fidx, __ffsll((long long)hm) - 1);
             const bool wother = __ballot(multi || (fidx != 0xffffffffu && fidx != widx)) != 0ull;
             if (lane == 0) {
                 ctl->pE[wv] = wd;
@@ -608,6 +644,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& u
             }
             amb = fl & 1;
             unique = unique && !(fl & 2) && bi != 0xffffffffu;
+            FINE(pf, 6);                                    // wave + workgroup reduction of the fp32 stage
             if (!amb) {
                 if (unique && (float)bd < -thr_scale - eps) {           // certain improving move
                     e = ((double)(float)bd + (double)eps) / ctl->sc;     // an upper bound, < -1e-6
@@ -661,6 +698,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& u
             exact_sweep(v, g.n, tid, g.nt, e, idx);
             block_best(ctl, tid, g.nt, e, idx);
         }
+        FINE(pf, 7);                                        // exact stage
         if (pf.on) pf.select += clock64() - t0;
     }
 }
@@ -670,6 +708,27 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& u
 template <int Q, typename T>
 __device__ __forceinline__ void put_xy(const View<T>& v, const Geo& g, int p, float x, float y)
 {
+    if (g.W + 4 <= 2 * g.n) {       // (uniform) at most two window copies: w = p and w = p + n
+        const int s0 = slot<Q>(p), w1 = p + g.n;
+        v.Xq[s0].x = x;
+        v.Yq[s0].x = y;
+        if (p >= 4) {
+            const int sb = slot<Q>(p - 4);
+            v.Xq[sb].y = x;
+            v.Yq[sb].y = y;
+        }
+        if (w1 < g.W + 4) {
+            const int sb = slot<Q>(w1 - 4);
+            v.Xq[sb].y = x;
+            v.Yq[sb].y = y;
+            if (w1 < g.W) {
+                const int s1 = slot<Q>(w1);
+                v.Xq[s1].x = x;
+                v.Yq[s1].x = y;
+            }
+        }
+        return;
+    }
     for (int w = p; w < g.W + 4; w += g.n) {
         if (w < g.W) {
             const int s = slot<Q>(w);
@@ -687,6 +746,16 @@ __device__ __forceinline__ void put_xy(const View<T>& v, const Geo& g, int p, fl
 template <int Q, typename T>
 __device__ __forceinline__ void put_e(const View<T>& v, const Geo& g, int p, float e)
 {
+    if (g.W + 4 <= 2 * g.n) {
+        const int w1 = p + g.n;
+        v.Eq[slot<Q>(p)].x = e;
+        if (p >= 4) v.Eq[slot<Q>(p - 4)].y = e;
+        if (w1 < g.W + 4) {
+            v.Eq[slot<Q>(w1 - 4)].y = e;
+            if (w1 < g.W) v.Eq[slot<Q>(w1)].x = e;
+        }
+        return;
+    }
     for (int w = p; w < g.W + 4; w += g.n) {
         if (w < g.W) v.Eq[slot<Q>(w)].x = e;
         if (w >= 4) v.Eq[slot<Q>(w - 4)].y = e;
@@ -695,9 +764,10 @@ __device__ __forceinline__ void put_e(const View<T>& v, const Geo& g, int p, flo
 
 // reverse tour[i+1..j] (two_opt.py:42) and keep the filter window consistent
 template <typename T, int Q>
-__device__ void apply_move(const View<T>& v, const Geo& g, int tid, unsigned idx)
+__device__ void apply_move(const View<T>& v, const Geo& g, int tid, unsigned idx, Prof& pf)
 {
     const int i = (int)(idx >> 16), j = (int)(idx & 0xffffu);
+    FINE_START(pf);
 
     const int L = j - i;
     const int h = L >> 1;
@@ -717,6 +787,7 @@ __device__ void apply_move(const View<T>& v, const Geo& g, int tid, unsigned idx
             }
         }
     }
+    FINE(pf, 8);                                // positions + coordinates + boundary edges
     if constexpr (Q != 0) {
         const int he = (L - 1) >> 1;            // interior edges i+1..j-1 are mirrored
         for (int k = tid; k < he; k += g.nt) {
@@ -726,7 +797,9 @@ __device__ void apply_move(const View<T>& v, const Geo& g, int tid, unsigned idx
             put_e<Q>(v, g, p2, a);
         }
     }
+    FINE(pf, 9);                                // interior edges
     __syncthreads();
+    FINE(pf, 10);                               // closing barrier
 }
 
 // ------------------------------------------------------------------------------------------
@@ -997,10 +1070,11 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
         bool have_prev = false, prev_active = false, active_at_target = false;
         unsigned prev_idx = kNoMove;
         unsigned last = kFullSweep;             // reversal applied since the previous sweep
+        float spd = 0.f;                        // thread 0: cached filter value of the pair (0, n-1)
         for (;;) {
             const bool check_only = forced && it >= target;
             if (check_only && target >= p.max_iter) break;
-            find_best<T, Q, CL>(v, g, tid, un, forced, last, e, idx, pf);
+            find_best<T, Q, CL>(v, g, tid, un, forced, last, spd, e, idx, pf);
             ++sweeps;
             unsigned xfl = 0;
             if constexpr (CL) {
@@ -1031,7 +1105,7 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
             }
             unsigned long long ta = 0;
             if (pf.on) ta = clock64();
-            apply_move<T, Q>(v, g, tid, idx);
+            apply_move<T, Q>(v, g, tid, idx, pf);
             last = idx;
             if (pf.on) pf.apply += clock64() - ta;
             if (stop_after) break;
@@ -1067,6 +1141,9 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
                 atomicAdd(&p.stamps[4], clock64() - t_tour);
                 atomicAdd(&p.stamps[5], (unsigned long long)pf.amb);
                 atomicAdd(&p.stamps[6], (unsigned long long)pf.cands);
+#ifdef TSP2OPT_FINE
+                for (int k = 0; k < 16; ++k) atomicAdd(&p.stamps[8 + k], pf.fine[k]);
+#endif
             }
         }
     }
@@ -1907,6 +1984,7 @@ Plan make_plan(int n, int dtype, int cs = 1)
             const int W = rows + 8 * GP + 8;            // multiple of 8
             const int q = W / 8 + 1;
             for (int qc : kQClasses) {
+                if (W >= 3 * n) break;                  // wrap3(): window positions must stay below 3n
                 if (qc >= q && base + (size_t)qc * 192 <= kLdsMax) {
                     g.qclass = qc; g.GP = GP; g.G = G; g.NS = NS; g.MS = MS;
                     g.W = W;

@@ -28,6 +28,7 @@ res = amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi, max_iterations=
 t1.record(); torch.cuda.synchronize()
 ws = list(two_opt._workspaces.values())[0]
 st = ws[64:128].cpu().numpy().view(np.uint64)
+fine = ws[128:256].cpu().numpy().view(np.uint64)
 print('amb events:', int(st[5]), 'exact-stage runs (single-WG) / wave0 cands (cluster)', int(st[6]), 'sweeps', int(res.sweeps.sum().item()))
 names = ["sweep", "select", "apply", "stage/exchange", "tour_total"]
 tot = float(st[4])
@@ -35,6 +36,12 @@ sw = int(res.sweeps.sum().item())
 print(f"{cfg} {dt.__name__}: {t0.elapsed_time(t1):.2f} ms (stamped build), plan={_lib.plan(pts.shape[1], 1 if dt==np.float64 else 0, 0)}")
 for n, v in zip(names, st):
     print(f"  {n:10s} {int(v):>16d} cycles  {100*float(v)/tot:6.2f} %   per sweep: {float(v)/sw:9.1f}")
+if fine.any():      # TSP2OPT_LIB=.../libtsp2opt_hip_fine.so (python -m ml4tspbench_amd.build --fine)
+    labels = ["sweep: mark+compact", "sweep: barrier+changed tiles", "sweep: barrier+cached minima", "sweep: full",
+              "select: wg filter min", "select: fp32 candidates", "select: fp32 reduction", "select: exact stage",
+              "apply: positions+coords", "apply: interior edges", "apply: barrier"]
+    for n, v in zip(labels, fine):
+        print(f"    {n:32s} per sweep: {float(v)/sw:9.1f}")
 L.tsp2opt_debug_phase_cycles(0)
 if pts.shape[1] > 2500 or len(tours) < 200:
     sys.exit(0)
