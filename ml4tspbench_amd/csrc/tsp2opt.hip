@@ -1367,11 +1367,12 @@ __device__ __forceinline__ float group_min_c(const CView<T>& v, const CGeo& g, i
 // every lane reduces the cached minima of its unit exactly as the full sweep would.
 template <typename T>
 __device__ __forceinline__ void sweep_c(const CView<T>& v, const CGeo& g, int tid, unsigned last,
-                                        float& a1, float& a2, unsigned& chunk)
+                                        float& a1, float& a2, unsigned& chunk, Prof& pf)
 {
     Ctl* ctl = v.ctl;
     const int units = g.GPw * g.NSw;
     bool full = !g.inc || last == kFullSweep;
+    FINE_START(pf);
     if (!full) {
         const int i = (int)(last >> 16), j = (int)(last & 0xffffu);
         const int gpl = tid % g.GPw, sl = tid / g.GPw;
@@ -1403,6 +1404,7 @@ __device__ __forceinline__ void sweep_c(const CView<T>& v, const CGeo& g, int ti
                 base += (unsigned)__popcll(b);
             }
         }
+        FINE(pf, 0);
         __syncthreads();
         const unsigned nl = ctl->nlist;
         if (nl > (unsigned)g.lcap) {
@@ -1416,6 +1418,7 @@ __device__ __forceinline__ void sweep_c(const CView<T>& v, const CGeo& g, int ti
             }
             __builtin_amdgcn_s_setprio(3);
         }
+        FINE(pf, 1);
         __syncthreads();
         if (tid == 0) ctl->nlist = 0;
         if (!full) {
@@ -1431,12 +1434,14 @@ __device__ __forceinline__ void sweep_c(const CView<T>& v, const CGeo& g, int ti
                     mc += units;
                 }
             }
+            FINE(pf, 2);
             return;
         }
     }
     __builtin_amdgcn_s_setprio(0);
     filter_sweep_c(v, g, tid, a1, a2, chunk);
     __builtin_amdgcn_s_setprio(3);
+    FINE(pf, 3);
 }
 
 template <typename T>
@@ -1477,7 +1482,7 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
     unsigned chunk;
     unsigned long long t0 = 0;
     if (pf.on) t0 = clock64();
-    sweep_c(v, g, tid, last, a1, a2, chunk);
+    sweep_c(v, g, tid, last, a1, a2, chunk, pf);
     if (pf.on) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
     const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
     const float wm = wave_min(a1);
@@ -1488,6 +1493,7 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
     const float thr = m + g.eps2;
     unsigned long long cmask = __ballot(a1 <= thr);
     int amb = __ballot(a2 <= thr) != 0ull || __popcll(cmask) > 8;
+    FINE(pf, 4);                                            // workgroup minimum of the filter (incl. barrier)
     if (pf.on) pf.cands += (unsigned)__popcll(cmask);
     const unsigned long long tc0 = pf.on ? clock64() : 0;
     e = 0.0;
@@ -1498,11 +1504,24 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
             cmask &= cmask - 1;
             const int id = __builtin_amdgcn_readlane((int)chunk, src);
             const int u = id / g.NG, m0 = (id - u * g.NG) * g.K;       // the K macro steps of the group
-            for (int pp = lane; pp < 32 * g.K; pp += 64) {
-                const int m = m0 + (pp >> 5);
+            // coarse groups: lane l recomputes the filter minimum of macro step m0 + l; only steps
+            // inside the window can hold the argmin (same bound as for the group) and go to the exact
+            // evaluation, 32 pairs each
+            unsigned long long sm = 1ull;
+            if (g.K > 1) {
+                float mm = INFINITY;
+                if (lane < g.K && m0 + lane < g.MS) {
+                    const int gpl = u % g.GPw, sl = u / g.GPw, m = m0 + lane;
+                    walk_c(v, g, 4 * (sl * g.MS + m), sl * g.MS + 2 * gpl + 1 + m, 1, [&](float x) { mm = x; });
+                }
+                sm = __ballot(mm <= thr);
+            }
+            while (sm) {
+                const int m = m0 + __builtin_amdgcn_readfirstlane(__ffsll((long long)sm) - 1);
+                sm &= sm - 1;
                 double d;
                 unsigned di;
-                if (m < g.MS && eval_chunk_pair_c(v, g, u, m, pp & 31, d, di) && better(d, di, e, idx)) {
+                if (lane < 32 && eval_chunk_pair_c(v, g, u, m, lane, d, di) && better(d, di, e, idx)) {
                     e = d;
                     idx = di;
                 }
@@ -1515,8 +1534,10 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
         wave_best(e, idx);
     }
     if (pf.on) pf.apply += 0, pf.candcyc += clock64() - tc0;
+    FINE(pf, 5);                                            // exact candidates of this wave
     if (lane == 0) { ctl->pE[wv] = e; ctl->pIdx[wv] = idx; ctl->pAmb[wv] = amb; }
     __syncthreads();
+    FINE(pf, 6);                                            // barrier: the other waves' candidates
     e = ctl->pE[0];
     idx = ctl->pIdx[0];
     amb = ctl->pAmb[0];
@@ -1665,8 +1686,10 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
             unsigned myflags = 0;
             if (wc == 0 && p.time_limit_ticks && wall_clock64() - t_start > p.time_limit_ticks)
                 myflags |= kFlagStop;
+            FINE_START(pf);
             if (!cluster_exchange(ctl, cs, g.CS, wc, epoch, tid, nt, myflags, e, idx, fl)) { aborted = true; break; }
             ++epoch;
+            FINE(pf, 11);                                                    // cluster exchange
             if (pf.on) { const unsigned long long t1 = clock64(); t_x += t1 - tb; tb = t1; }
             if (!(e < -1.0e-6)) break;                                       // two_opt.py:40
             const int i = (int)(idx >> 16), j = (int)(idx & 0xffffu);
@@ -1677,8 +1700,11 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
                 v.tour[j - k] = a;
             }
             __syncthreads();
+            FINE(pf, 8);                                                     // tour reversal
             stage_c(v, g, tid, i + 1, j, i, j);
+            FINE(pf, 9);                                                     // restaging of the filter copy
             __syncthreads();
+            FINE(pf, 10);
             last = idx;
             if (pf.on) pf.apply += clock64() - tb;
             ++it;
@@ -1695,6 +1721,9 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
             atomicAdd(&p.stamps[6], (unsigned long long)pf.cands);
             atomicAdd(&p.stamps[7], pf.candcyc);
             atomicAdd(&p.stamps[4], clock64() - t_tour);
+#ifdef TSP2OPT_FINE
+            for (int k = 0; k < 16; ++k) atomicAdd(&p.stamps[8 + k], pf.fine[k]);
+#endif
         }
         if (aborted) {
             if (wc == 0 && tid == 0 && p.status) p.status[tk] = TSP2OPT_ST_INTERNAL;

@@ -39,7 +39,7 @@ for n, v in zip(names, st):
 if fine.any():      # TSP2OPT_LIB=.../libtsp2opt_hip_fine.so (python -m ml4tspbench_amd.build --fine)
     labels = ["sweep: mark+compact", "sweep: barrier+changed tiles", "sweep: barrier+cached minima", "sweep: full",
               "select: wg filter min", "select: fp32 candidates", "select: fp32 reduction", "select: exact stage",
-              "apply: positions+coords", "apply: interior edges", "apply: barrier"]
+              "apply: positions+coords", "apply: interior edges", "apply: barrier", "cluster exchange"]
     for n, v in zip(labels, fine):
         print(f"    {n:32s} per sweep: {float(v)/sw:9.1f}")
 L.tsp2opt_debug_phase_cycles(0)
