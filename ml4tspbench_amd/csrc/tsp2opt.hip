@@ -564,7 +564,14 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& u
         __syncthreads();
         float m = ctl->wmin[0];
         for (int w = 1; w < nw; ++w) m = fminf(m, ctl->wmin[w]);
-        const float thr = m + g.eps2;
+        float thr = m + g.eps2;
+        if constexpr (CL) {
+            // This workgroup sees only its own tiles, whose minimum may be far above the tour's.  Only
+            // moves below -1e-6 are ever applied (independent termination), so pairs whose filter value
+            // proves delta >= -1e-6 need no exact evaluation: without this clamp a workgroup whose tiles
+            // hold no improving move would chase near-ties among its non-improving minima.
+            thr = fminf(thr, (float)(-1.0e-6 * ctl->sc) + 0.625f * g.eps2);
+        }
         const unsigned long long cmask0 = __ballot(a1 <= thr);
         int amb = __ballot(a2 <= thr) != 0ull || __popcll(cmask0) > 8;
         FINE(pf, 4);                                        // workgroup minimum of the filter
@@ -693,10 +700,48 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& u
             const unsigned oi = ctl->pIdx[w];
             if (better(oe, oi, e, idx)) { e = oe; idx = oi; }
         }
-        if (amb) {      // a lane holds two macro steps inside the window: exact sweep this iteration
+        if (amb) {
+            // A lane holds two tiles inside the window (or a wave more than 8 candidates): the per-lane
+            // best/runner-up no longer names every candidate.  With the tile cache, every candidate is
+            // still known -- all tiles whose cached minimum is inside the window -- and is evaluated
+            // exactly, one tile per wave at a time; only without the cache (or if even that list
+            // overflows: heavy ties, e.g. grids) the whole tour is swept exactly.
             __syncthreads();
-            exact_sweep(v, g.n, tid, g.nt, e, idx);
-            block_best(ctl, tid, g.nt, e, idx);
+            bool listed = false;
+            if (g.inc) {
+                const int tiles = g.GPl * g.NS * (g.MS >> 1);
+                for (int t = tid; t < tiles; t += g.nt) {
+                    const int gpl = t % g.GPl;
+                    if (v.Mc[t] <= thr && g.wc + g.CS * gpl < g.GP) {
+                        const unsigned pos = atomicAdd(&ctl->nlist, 1u);
+                        if (pos < (unsigned)g.lcap) v.list[pos] = (uint16_t)(((unsigned)(t / g.GPl) << 8) | (unsigned)gpl);
+                    }
+                }
+                __syncthreads();
+                const unsigned nl = ctl->nlist;
+                __syncthreads();
+                if (tid == 0) ctl->nlist = 0;
+                if (nl <= (unsigned)g.lcap) {
+                    listed = true;
+                    e = 0.0;
+                    idx = kNoMove;
+                    for (unsigned c = (unsigned)wv; c < nl; c += (unsigned)nw) {
+                        double d;
+                        unsigned di;
+                        eval_chunk_pair(v, g, v.list[c], lane, d, di);
+                        if (better(d, di, e, idx)) { e = d; idx = di; }
+                    }
+                    if (tid == 0) {
+                        const double d = exact_delta(v, 0, g.n - 1);
+                        if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
+                    }
+                    block_best(ctl, tid, g.nt, e, idx);
+                }
+            }
+            if (!listed) {
+                exact_sweep(v, g.n, tid, g.nt, e, idx);
+                block_best(ctl, tid, g.nt, e, idx);
+            }
         }
         FINE(pf, 7);                                        // exact stage
         if (pf.on) pf.select += clock64() - t0;
@@ -1490,7 +1535,9 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
     __syncthreads();
     float m = ctl->wmin[0];
     for (int w = 1; w < nw; ++w) m = fminf(m, ctl->wmin[w]);
-    const float thr = m + g.eps2;
+    // only moves below -1e-6 are ever applied: pairs whose filter value proves delta >= -1e-6 need no
+    // exact evaluation (a tile without improving moves must not chase ties among its own minima)
+    const float thr = fminf(m + g.eps2, (float)(-1.0e-6 * v.sc) + 0.625f * g.eps2);
     unsigned long long cmask = __ballot(a1 <= thr);
     int amb = __ballot(a2 <= thr) != 0ull || __popcll(cmask) > 8;
     FINE(pf, 4);                                            // workgroup minimum of the filter (incl. barrier)

@@ -66,11 +66,19 @@ def main():
     ap.add_argument("--knn", type=int, default=0)
     ap.add_argument("--check", type=int, default=2, help="instances checked against the CPU oracles")
     ap.add_argument("--max-iterations", type=int, default=5000)
+    ap.add_argument("--cluster-mode", type=int, default=-1, help="diagnostic, see bench.py")
+    ap.add_argument("--phases", action="store_true", help="diagnostic: phase cycles of one extra 2-opt run")
+    ap.add_argument("--tune", action="append", default=[], help="diagnostic: tsp2opt_debug_tune what=value")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs an MI355X")
     dev = torch.device("cuda", 0)
     import ml4tspbench_amd as amd
+    from ml4tspbench_amd import _lib
+    _lib.lib().tsp2opt_debug_cluster_mode(args.cluster_mode)
+    for kv in args.tune:
+        k_, v_ = kv.split("=")
+        _lib.lib().tsp2opt_debug_tune(int(k_), int(v_))
 
     n, inst, per = CONFIGS[args.config]
     rng = np.random.default_rng(1234)
@@ -115,6 +123,22 @@ def main():
         "mean_length_after_2opt": float(sel.lengths.mean().item()),
         "mean_length_best_of_p": float(sel.best_length.mean().item()),
     }
+    if args.phases:
+        from ml4tspbench_amd import two_opt
+        L = _lib.lib()
+        L.tsp2opt_debug_phase_cycles(1)
+        r2 = amd.two_opt_device(pts, tours, tours_per_instance=per, group_size=1,
+                                max_iterations=args.max_iterations, want_lengths=False)
+        torch.cuda.synchronize()
+        L.tsp2opt_debug_phase_cycles(0)
+        ws = list(two_opt._workspaces.values())[0]
+        st = ws[64:256].cpu().numpy().view(np.uint64)
+        sw = float(r2.sweeps.sum().item())
+        names = ["sweep", "select", "apply", "stage/exchange", "tour_total", "amb events", "exact-stage runs", "cand cycles",
+                 "sweep: mark+compact", "sweep: barrier+changed tiles", "sweep: barrier+cached minima", "sweep: full",
+                 "select: wg filter min", "select: fp32 candidates", "select: fp32 reduction", "select: exact stage",
+                 "apply: positions+coords", "apply: interior edges", "apply: barrier", "cluster exchange"]
+        out["phase_cycles_per_sweep"] = {nm: round(float(x) / sw, 2) for nm, x in zip(names, st) if x}
     if args.check:
         from oracle import greedy_oracle, two_opt_oracle
         c = min(args.check, inst)
