@@ -1517,6 +1517,35 @@ __device__ __forceinline__ bool eval_chunk_pair_c(const CView<T>& v, const CGeo&
     return true;
 }
 
+// exact evaluation of step group `id` (wave-uniform) by one wave: folds the group's pairs into (e, idx)
+template <typename T>
+__device__ __forceinline__ void eval_group_c(const CView<T>& v, const CGeo& g, int id, float thr, int lane,
+                                             double& e, unsigned& idx)
+{
+    const int u = id / g.NG, m0 = (id - u * g.NG) * g.K;       // the K macro steps of the group
+    // coarse groups: lane l recomputes the filter minimum of macro step m0 + l; only steps inside the
+    // window can hold the argmin (same bound as for the group) and go to the exact evaluation
+    unsigned long long sm = 1ull;
+    if (g.K > 1) {
+        float mm = INFINITY;
+        if (lane < g.K && m0 + lane < g.MS) {
+            const int gpl = u % g.GPw, sl = u / g.GPw, m = m0 + lane;
+            walk_c(v, g, 4 * (sl * g.MS + m), sl * g.MS + 2 * gpl + 1 + m, 1, [&](float x) { mm = x; });
+        }
+        sm = __ballot(mm <= thr);
+    }
+    while (sm) {
+        const int m = m0 + __builtin_amdgcn_readfirstlane(__ffsll((long long)sm) - 1);
+        sm &= sm - 1;
+        double d;
+        unsigned di;
+        if (lane < 32 && eval_chunk_pair_c(v, g, u, m, lane, d, di) && better(d, di, e, idx)) {
+            e = d;
+            idx = di;
+        }
+    }
+}
+
 // best move of this workgroup's tile: e = min(0, min exact delta), idx packed; valid in all threads
 template <typename T>
 __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool first_wg, unsigned last,
@@ -1549,30 +1578,7 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
         while (cmask) {
             const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)cmask) - 1);
             cmask &= cmask - 1;
-            const int id = __builtin_amdgcn_readlane((int)chunk, src);
-            const int u = id / g.NG, m0 = (id - u * g.NG) * g.K;       // the K macro steps of the group
-            // coarse groups: lane l recomputes the filter minimum of macro step m0 + l; only steps
-            // inside the window can hold the argmin (same bound as for the group) and go to the exact
-            // evaluation, 32 pairs each
-            unsigned long long sm = 1ull;
-            if (g.K > 1) {
-                float mm = INFINITY;
-                if (lane < g.K && m0 + lane < g.MS) {
-                    const int gpl = u % g.GPw, sl = u / g.GPw, m = m0 + lane;
-                    walk_c(v, g, 4 * (sl * g.MS + m), sl * g.MS + 2 * gpl + 1 + m, 1, [&](float x) { mm = x; });
-                }
-                sm = __ballot(mm <= thr);
-            }
-            while (sm) {
-                const int m = m0 + __builtin_amdgcn_readfirstlane(__ffsll((long long)sm) - 1);
-                sm &= sm - 1;
-                double d;
-                unsigned di;
-                if (lane < 32 && eval_chunk_pair_c(v, g, u, m, lane, d, di) && better(d, di, e, idx)) {
-                    e = d;
-                    idx = di;
-                }
-            }
+            eval_group_c(v, g, __builtin_amdgcn_readlane((int)chunk, src), thr, lane, e, idx);
         }
         if (first_wg && tid == 32) {        // the pair (0, n-1), once per tour
             const double d = exact_delta_c(v, 0, g.n - 1);
@@ -1595,18 +1601,44 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
         if (better(oe, oi, e, idx)) { e = oe; idx = oi; }
     }
     if (pf.on) { pf.amb += amb ? 1 : 0; }
-    if (amb) {      // two candidates in one lane: evaluate the whole tile exactly this iteration
+    if (amb) {
+        // Two candidate groups in one lane (or more than 8 per wave).  With the cache every candidate
+        // is still known (all groups whose cached minimum is inside the window) and is evaluated
+        // exactly, one group per wave at a time; without it (or if that list overflows) the whole tile
+        // of this workgroup is evaluated exactly.
         __syncthreads();
+        bool listed = false;
         e = 0.0;
         idx = kNoMove;
-        const long long total = (long long)g.GPw * g.NSw * g.MS * 32;
-        for (long long k = tid; k < total; k += g.nt) {
-            double d;
-            unsigned di;
-            const int ms = (int)(k >> 5);
-            if (eval_chunk_pair_c(v, g, ms / g.MS, ms % g.MS, (int)(k & 31), d, di) && better(d, di, e, idx)) {
-                e = d;
-                idx = di;
+        if (g.inc) {
+            const int units = g.GPw * g.NSw, groups = units * g.NG;
+            for (int t = tid; t < groups; t += g.nt) {
+                const int q = t / units, u = t - q * units;
+                if (v.Mc[t] <= thr && v.gp0 + u % g.GPw < g.GP) {
+                    const unsigned pos = atomicAdd(&ctl->nlist, 1u);
+                    if (pos < (unsigned)g.lcap) v.list[pos] = (uint16_t)(u * g.NG + q);
+                }
+            }
+            __syncthreads();
+            const unsigned nl = ctl->nlist;
+            __syncthreads();
+            if (tid == 0) ctl->nlist = 0;
+            if (nl <= (unsigned)g.lcap) {
+                listed = true;
+                for (unsigned c = (unsigned)wv; c < nl; c += (unsigned)nw)
+                    eval_group_c(v, g, (int)v.list[c], thr, lane, e, idx);
+            }
+        }
+        if (!listed) {
+            const long long total = (long long)g.GPw * g.NSw * g.MS * 32;
+            for (long long k = tid; k < total; k += g.nt) {
+                double d;
+                unsigned di;
+                const int ms = (int)(k >> 5);
+                if (eval_chunk_pair_c(v, g, ms / g.MS, ms % g.MS, (int)(k & 31), d, di) && better(d, di, e, idx)) {
+                    e = d;
+                    idx = di;
+                }
             }
         }
         if (first_wg && tid == 0) {
