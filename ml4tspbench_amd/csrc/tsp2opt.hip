@@ -2052,7 +2052,8 @@ constexpr size_t kCsyncBytes = 64 * 1024;   // cluster barrier words + slots (<=
 const int kQClasses[] = {16, 32, 64, 128, 256, 512};
 
 int g_force_nt = 0;         // diagnostic: threads per workgroup of the single-workgroup plan
-int g_lcap16 = 8;           // diagnostic: changed-group list capacity of the cluster kernel, in 1/16 of the groups
+int g_lcap16 = 13;          // diagnostic: changed-group list capacity of the cluster kernel, in 1/16 of the groups
+int g_lcap16s = 13;         // changed-tile list capacity of the one-workgroup / full-window kernel, in 1/16 of the tiles
 int g_inc_min_tiles = 2;    // tile cache only when a lane owns at least this many tiles (measured: TSP-50 / TSP-100)
 
 // cs > 1: geometry of one workgroup of a full-window cluster of cs workgroups (lane groups interleaved)
@@ -2101,14 +2102,15 @@ Plan make_plan(int n, int dtype, int cs = 1)
                 }
             }
             if (g.qclass) {
-                // minimum cache (4 B per tile) + changed-tile list (2 B per entry, half the tiles: measured,
-                // beyond that a plain sweep is cheaper than recomputing tile by tile)
+                // minimum cache (4 B per tile) + changed-tile list (2 B per entry, 13/16 of the tiles: measured
+                // on TSP-100/500/1000, beyond that a plain sweep is cheaper than recomputing tile by tile)
                 const size_t tiles = (size_t)GPl * NS * (MS / 2);
-                const size_t need = align16(4 * tiles) + align16(2 * (tiles / 2 + 1));
+                const size_t lcap = tiles * (size_t)g_lcap16s / 16 + 1;
+                const size_t need = align16(4 * tiles) + align16(2 * lcap);
                 if (MS / 2 >= g_inc_min_tiles && (size_t)NS * (MS / 2) <= 255 && GPl <= 255 && MS / 2 <= 64 && GPl * NS <= nt &&
                     base + (size_t)g.qclass * 192 + need <= kLdsMax) {
                     g.inc = 1;
-                    g.lcap = (int)(tiles / 2 + 1);
+                    g.lcap = (int)lcap;
                     cache = need;
                 }
             }
@@ -2684,6 +2686,7 @@ extern "C" int tsp2opt_debug_tune(int32_t what, int32_t value)
     else if (what == 1) g_lcap16 = value < 1 ? 1 : value > 16 ? 16 : value;
     else if (what == 2) g_inc_min_tiles = value;
     else if (what == 3) g_cluster_variant = value;
+    else if (what == 4) g_lcap16s = value < 1 ? 1 : value > 16 ? 16 : value;
     else return fail(TSP2OPT_E_ARG, "unknown tuning knob");
     return 0;
 }
