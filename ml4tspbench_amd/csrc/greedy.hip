@@ -16,17 +16,23 @@
 //
 // Two kernels.  k_greedy_prepare (fully parallel) turns every heat map into the matrix of edge
 // keys, S = A + A^T formed on the fly through a tiled transpose so that A and A^T are both read
-// coalesced, and finds each node's first candidate.  k_greedy runs the merge loop, one WAVE per
-// heat map (no workgroup barriers; every step is a short latency chain and many heat maps run side
-// by side on a CU), with per-map state in LDS: candidate key (double, plus its fp32 rounding) and
-// partner, degree, the other endpoint of each fragment, two neighbour slots.  A rescan is one
-// coalesced read of the node's key row: a single global round trip.
+// coalesced, and extracts every node's (up to) kTopK best partners in exact (key, index) order from the
+// two best entries each lane saw in its own columns.  k_greedy runs the merge loop, one WAVE per heat map (no workgroup barriers;
+// every step is a short latency chain and many heat maps run side by side on a CU), with per-map
+// state in LDS: the fp32 rounding of each node's candidate key and its partner, the node's short
+// candidate list and a cursor into it, degree, the other endpoint of each fragment, two neighbour
+// slots, and the minimum candidate key of every group of 64 nodes.  An invalidated candidate is
+// replaced by the next still-valid entry of the node's list (validity only decays, so skipped
+// entries never come back) -- LDS only, 3 of 4 replacements -- and by a rescan of the node's key row
+// (one global round trip) once the list is used up.  The best candidate over all nodes is the
+// minimum of the group minima; only the groups of the one or two nodes that changed are refreshed.
 //
 // Arithmetic follows the reference: S is summed in the heat map's dtype (numpy adds float32 arrays
 // in float32, greedy_search.py:36-38), keys are -double(S)/sqrt(dx*dx+dy*dy) in double
 // (cython_merge.pyx:23,37).  The per-step choice among the nodes' candidates first compares the
 // fp32 ROUNDINGS of the keys, which is monotone: the exact minimum is among the entries equal to
-// the fp32 minimum, and only those are compared in double.  Where two different edges have
+// the fp32 minimum, and only those are compared in double (fetched from the key matrix; the common
+// tie, two nodes naming each other, is the same edge and needs no fetch).  Where two different edges have
 // exactly equal keys the reference's order is numpy's unstable argsort order; here (and in the
 // oracle) the lower flat index wins.
 
@@ -44,14 +50,62 @@
 
 namespace t2o {
 
-// Kd[b][i][j] = key of edge (i, j) (+inf on the diagonal and for NaN, which numpy sorts last);
-// ckey/cj[b][i] = the row's minimum (key, j).  Block (64, 4): a band of 32 rows (8 per thread),
-// column tiles of 64; the transposed operand goes through LDS.
-template <typename H>
-__global__ void __launch_bounds__(256) k_greedy_prepare(const H* __restrict__ A, const double* __restrict__ points,
-                                                        double* __restrict__ Kd, double* __restrict__ ckey,
-                                                        unsigned* __restrict__ cj, int n, int maps_per_instance,
-                                                        int64_t map0)
+// A row's best partners in exact (key, j) order, from the two best entries every lane has seen among
+// its own columns (j = lane mod 64): lkey (fp32 rounding, NaN = no entry) and lj (0xffff = no entry).
+// Each round takes the best head over the wave (fp32 first, exact on fp32 ties) and the owner pops.
+// A lane that has popped both its entries no longer knows its next best, so the extraction stops
+// there: the list is then shorter than `rounds` but still an exact prefix of the row's order (the
+// merge loop falls back to a row rescan once a list is used up).
+constexpr int kTopK = 4;
+
+__device__ __forceinline__ void row_topk(double k0, unsigned j0, double k1, unsigned j1, int lane, int rounds,
+                                         float* __restrict__ lkey, uint16_t* __restrict__ lj)
+{
+    int popped = 0;
+    int r = 0;
+#pragma unroll 1
+    for (; r < rounds; ++r) {
+        if (__ballot(popped == 2)) break;               // somebody's next best is unknown
+        // an empty head (j = 0xffff) must lose against any real entry, also one whose key is +inf:
+        // compare the fp32 key AND the presence bit
+        const bool has = j0 != 0xffffu;
+        const float hf = has ? (float)k0 : INFINITY;
+        const float m = wave_min(hf);
+        const unsigned long long bal = __ballot(has && hf == m);
+        if (!bal) break;                                // nothing left in this row
+        unsigned bj;
+        if (__popcll(bal) == 1) {
+            bj = (unsigned)__builtin_amdgcn_readlane((int)j0, __ffsll((long long)bal) - 1);
+        } else {                                        // fp32 tie: exact (key, j)
+            double bk = (has && hf == m) ? k0 : INFINITY;
+            bj = (has && hf == m) ? j0 : 0xffffffffu;
+            wave_best(bk, bj);
+        }
+        if (lane == 0) {
+            lkey[r] = m;
+            lj[r] = (uint16_t)bj;
+        }
+        if (has && j0 == bj) {                          // the owner pops its head
+            k0 = k1; j0 = j1;
+            k1 = INFINITY; j1 = 0xffffu;
+            ++popped;
+        }
+    }
+    if (lane >= r && lane < kTopK) {                    // unused entries
+        lkey[lane] = __builtin_nanf("");
+        lj[lane] = 0xffffu;
+    }
+}
+
+// Kd[b][i][j] = key of edge (i, j) (+inf on the diagonal and for NaN, which numpy sorts last).
+// Block (64, 8): a band of 32 rows (4 per thread), column tiles of 64; the transposed operand goes
+// through LDS.
+// TK = entries tracked per lane and row (2, or 1 for small n where only the row's best is extracted)
+template <typename H, int TK>
+__global__ void __launch_bounds__(512) k_greedy_prepare(const H* __restrict__ A, const double* __restrict__ points,
+                                                        double* __restrict__ Kd, float* __restrict__ lkey,
+                                                        uint16_t* __restrict__ lj, int n, int maps_per_instance,
+                                                        int64_t map0, int topk_rounds)
 {
     __shared__ H tile[64][33];                          // tile[c][r] = A[c0 + c][i0 + r]
     const int64_t b = map0 + blockIdx.y;
@@ -60,38 +114,38 @@ __global__ void __launch_bounds__(256) k_greedy_prepare(const H* __restrict__ A,
     const H* Ab = A + (size_t)b * n * n;
     double* Kb = Kd + (size_t)b * n * n;
     const double* P = points + (size_t)(b / maps_per_instance) * n * 2;
-    double rx[8], ry[8], bk[8];
-    unsigned bj[8];
+    double rx[4], ry[4], b1k[4], b2k[4];                // b1/b2: this lane's two best (key, j) of the row
+    unsigned b1j[4], b2j[4];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        const int i = i0 + y + 4 * rr;
+    for (int rr = 0; rr < 4; ++rr) {
+        const int i = i0 + y + 8 * rr;
         rx[rr] = i < n ? P[2 * i] : 0.0;
         ry[rr] = i < n ? P[2 * i + 1] : 0.0;
-        bk[rr] = INFINITY;
-        bj[rr] = 0xffffu;
+        b1k[rr] = b2k[rr] = INFINITY;
+        b1j[rr] = b2j[rr] = 0xffffu;
     }
     for (int c0 = 0; c0 < n; c0 += 64) {
         // both operands' global loads are issued before the barrier: one round trip per tile
         const int j = c0 + x;
-        H a[8], tr[8];
+        H a[4], tr[4];
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int i = i0 + y + 4 * rr;
+        for (int rr = 0; rr < 4; ++rr) {
+            const int i = i0 + y + 8 * rr;
             a[rr] = (i < n && j < n) ? Ab[(size_t)i * n + j] : (H)0;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int c = (t >> 5) + 8 * k, r = t & 31;
+        for (int k = 0; k < 4; ++k) {
+            const int c = (t >> 5) + 16 * k, r = t & 31;
             const int jr = c0 + c, ic = i0 + r;
             tr[k] = (jr < n && ic < n) ? Ab[(size_t)jr * n + ic] : (H)0;
         }
         const double cx = j < n ? P[2 * j] : 0.0, cy = j < n ? P[2 * j + 1] : 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) tile[(t >> 5) + 8 * k][t & 31] = tr[k];
+        for (int k = 0; k < 4; ++k) tile[(t >> 5) + 16 * k][t & 31] = tr[k];
         __syncthreads();
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int r = y + 4 * rr, i = i0 + r;
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = y + 8 * rr, i = i0 + r;
             if (i < n && j < n) {
                 double k = INFINITY;
                 if (j != i) {
@@ -99,20 +153,30 @@ __global__ void __launch_bounds__(256) k_greedy_prepare(const H* __restrict__ A,
                     const double dx = rx[rr] - cx, dy = ry[rr] - cy;
                     k = -(double)s / sqrt(dx * dx + dy * dy);
                     k = k != k ? INFINITY : k;
-                    if (k < bk[rr] || (k == bk[rr] && (unsigned)j < bj[rr])) { bk[rr] = k; bj[rr] = (unsigned)j; }
+                    if constexpr (TK == 1) {
+                        if (better(k, (unsigned)j, b1k[rr], b1j[rr])) { b1k[rr] = k; b1j[rr] = (unsigned)j; }
+                    } else if (better(k, (unsigned)j, b2k[rr], b2j[rr])) {
+                        if (better(k, (unsigned)j, b1k[rr], b1j[rr])) {
+                            b2k[rr] = b1k[rr]; b2j[rr] = b1j[rr];
+                            b1k[rr] = k; b1j[rr] = (unsigned)j;
+                        } else {
+                            b2k[rr] = k; b2j[rr] = (unsigned)j;
+                        }
+                    }
                 }
                 Kb[(size_t)i * n + j] = k;
             }
         }
         __syncthreads();
     }
+    // candidate lists: the 64 lanes of wave y hold row y + 8 rr
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {                    // the 64 lanes of wave y hold row y + 4 rr
-        const int i = i0 + y + 4 * rr;
-        double k = bk[rr];
-        unsigned j = bj[rr];
-        wave_best(k, j);
-        if (x == 0 && i < n) { ckey[(size_t)b * n + i] = k; cj[(size_t)b * n + i] = j; }
+    for (int rr = 0; rr < 4; ++rr) {
+        const int i = i0 + y + 8 * rr;
+        if (i < n) {
+            const size_t row = (size_t)b * n + i;
+            row_topk(b1k[rr], b1j[rr], b2k[rr], b2j[rr], x, topk_rounds, lkey + row * kTopK, lj + row * kTopK);
+        }
     }
 }
 
@@ -121,125 +185,177 @@ __global__ void __launch_bounds__(256) k_greedy_prepare(const H* __restrict__ A,
 __device__ unsigned long long g_greedy_prof[8];
 
 struct GreedyLds {          // carve of the dynamic LDS for one heat map (one wave)
-    double* ckey;           // exact key of node i's candidate edge i -> cj[i]
-    float* capx;            // its fp32 rounding; NaN = node has no candidate (interior / none left)
+    float* capx;            // fp32 rounding of the key of node i's candidate edge i -> cj[i]; NaN = none
+    float* gmin;            // minimum of capx over every group of 64 nodes (+inf: no candidate in the group)
+    float* lk;              // K list entries per node: fp32 key (NaN = none) ...
+    uint16_t* lj;           // ... and partner (0xffff = none), exact (key, j) order
     uint16_t* cj;           // candidate partner
     uint16_t* oend;         // for a fragment endpoint: the fragment's other endpoint (itself if alone)
     uint16_t* nb;           // 2 neighbour slots per node, 0xffff = empty
     uint8_t* deg;
+    uint8_t* lp;            // cursor into the node's list (K: list used up, candidates come from rescans)
 };
 
-// best valid partner of node i: minimum (key, j) over j that are fragment endpoints of another
-// fragment.  All 64 lanes; result stored by lane 0.  The row's keys are loaded unconditionally,
-// eight per lane in flight, so a rescan costs one global round trip for n <= 512.
+// refresh the minimum of node x's group after capx[x] changed (all 64 lanes)
+__device__ __forceinline__ void refresh_group(const GreedyLds& L, int n, int x, int lane)
+{
+    if (n <= 128) return;                               // two groups at most: scanned directly
+    const int g = x >> 6, k = (g << 6) + lane;
+    const float v = k < n ? L.capx[k] : __builtin_nanf("");
+    const float m = wave_min(v != v ? INFINITY : v);
+    if (lane == 0) L.gmin[g] = m;
+}
+
+// can node i still take partner j?  (j is a fragment endpoint of another fragment)
+__device__ __forceinline__ bool partner_ok(const GreedyLds& L, int i, int oe, int j)
+{
+    return j != 0xffff && L.deg[j] < 2 && !(j == oe && oe != i);
+}
+
+// best valid partner of node i from its key row: minimum (key, j) over valid j.  All 64 lanes; the
+// row's keys are loaded unconditionally, W per lane in flight (8: n <= 512 in one global round trip
+// within 64 VGPRs, i.e. 8 heat maps per SIMD; 16 for larger n, where there are fewer maps than
+// SIMDs anyway).  Result stored by lane 0.
+template <int W>
 __device__ __forceinline__ void rescan(const GreedyLds& L, const double* __restrict__ Kb, int n, int i, int lane)
 {
     const double* Krow = Kb + (size_t)i * n;
     const int oe = L.oend[i];
     double bk = INFINITY;
     unsigned bj = 0xffffu;
-    for (int j0 = lane; j0 < n; j0 += 512) {
-        double k[8];
+    for (int j0 = lane; j0 < n; j0 += 64 * W) {
+        double k[W];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) k[u] = j0 + 64 * u < n ? Krow[j0 + 64 * u] : INFINITY;
+        for (int u = 0; u < W; ++u) k[u] = j0 + 64 * u < n ? Krow[j0 + 64 * u] : INFINITY;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < W; ++u) {
             const int j = j0 + 64 * u;
-            if (j >= n || j == i || L.deg[j] >= 2 || (j == oe && oe != i)) continue;
+            if (j >= n || j == i || !partner_ok(L, i, oe, j)) continue;
             if (k[u] < bk || (k[u] == bk && (unsigned)j < bj)) { bk = k[u]; bj = (unsigned)j; }
         }
     }
     wave_best(bk, bj);
     if (lane == 0) {
-        L.ckey[i] = bk;
         L.cj[i] = (uint16_t)bj;
         L.capx[i] = bj == 0xffffu ? __builtin_nanf("") : (float)bk;
     }
 }
 
-// n <= 64 U: minimum of the candidates' fp32 keys over the wave, how many nodes attain it, and one of them
-template <int U>
-__device__ __forceinline__ void scan_small(const GreedyLds& L, int n, int lane, float& m, int& i, int& hits)
+// node i's candidate is no longer valid: the next valid entry of its list, else a rescan
+__device__ __forceinline__ bool advance(const GreedyLds& L, int K, int i, int lane)
 {
-    float a[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) a[u] = lane + 64 * u < n ? L.capx[lane + 64 * u] : __builtin_nanf("");
-    float la = INFINITY;
-#pragma unroll
-    for (int u = 0; u < U; ++u) la = fminf(la, a[u]);
-    m = wave_min(la);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const unsigned long long bal = __ballot(a[u] == m);
-        if (bal) { hits += __popcll(bal); i = 64 * u + __ffsll((long long)bal) - 1; }
+    const int p0 = L.lp[i], oe = L.oend[i];
+    bool ok = false;
+    if (lane > p0 && lane < K) ok = partner_ok(L, i, oe, L.lj[i * K + lane]);
+    const unsigned long long bal = __ballot(ok);
+    if (!bal) {
+        if (lane == 0) L.lp[i] = (uint8_t)K;
+        return false;
     }
+    const int p = __ffsll((long long)bal) - 1;
+    if (lane == 0) {
+        L.lp[i] = (uint8_t)p;
+        L.cj[i] = L.lj[i * K + p];
+        L.capx[i] = L.lk[i * K + p];
+    }
+    return true;
 }
 
-__global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, const double* __restrict__ ckey0,
-                                              const unsigned* __restrict__ cj0, int64_t* __restrict__ tours,
-                                              int64_t num_maps, int n, int prof)
+// K = list entries kept per node in LDS (kTopK, or fewer when n is large); W: see rescan
+template <int W>
+__global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, const float* __restrict__ lkey,
+                                              const uint16_t* __restrict__ lj0, int64_t* __restrict__ tours,
+                                              int64_t num_maps, int n, int K, int prof)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int64_t b = blockIdx.x;
     if (b >= num_maps) return;
     const int lane = threadIdx.x;
+    const int G = (n + 63) >> 6;                        // groups of 64 nodes, <= 128
     GreedyLds L;
     size_t off = 0;
-    L.ckey = reinterpret_cast<double*>(smem + off); off += sizeof(double) * (size_t)n;
     L.capx = reinterpret_cast<float*>(smem + off); off += sizeof(float) * (size_t)n;
+    L.gmin = reinterpret_cast<float*>(smem + off); off += sizeof(float) * 128;
+    L.lk = reinterpret_cast<float*>(smem + off); off += sizeof(float) * (size_t)n * K;
+    L.lj = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n * K;
     L.cj = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n;
     L.oend = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n;
     L.nb = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * 2 * (size_t)n;
-    L.deg = reinterpret_cast<uint8_t*>(smem + off);
+    L.deg = reinterpret_cast<uint8_t*>(smem + off); off += (size_t)n;
+    L.lp = reinterpret_cast<uint8_t*>(smem + off);
     const double* Kb = Kd + (size_t)b * (size_t)n * (size_t)n;
     for (int i = lane; i < n; i += 64) {
         L.oend[i] = (uint16_t)i;
         L.nb[2 * i] = L.nb[2 * i + 1] = 0xffffu;
         L.deg[i] = 0;
+        L.lp[i] = 0;
+        const size_t src = ((size_t)b * n + i) * kTopK;
+        for (int p = 0; p < K; ++p) {
+            L.lk[i * K + p] = lkey[src + p];
+            L.lj[i * K + p] = lj0[src + p];
+        }
+        L.capx[i] = lkey[src];                          // first candidates: the heads of the lists
+        L.cj[i] = lj0[src];
     }
     __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < n; i += 64) {               // first candidates: from the prepare kernel
-        const double k = ckey0[(size_t)b * n + i];
-        L.ckey[i] = k;
-        L.cj[i] = (uint16_t)cj0[(size_t)b * n + i];
-        L.capx[i] = (float)k;
-    }
+    for (int g = 0; g < G; ++g) refresh_group(L, n, g << 6, lane);
     __builtin_amdgcn_wave_barrier();
 
     int merges = 0;
     unsigned long long t_scan = 0, t_merge = 0, t_rescan = 0, n_rescan = 0, t_begin = prof ? clock64() : 0;
-    // every pass either merges or rescans one node; a node is rescanned at most once per change of
-    // validity of its candidate, so the loop ends (bounded anyway: never spin forever on bad input)
+    // every pass either merges or replaces one node's candidate; a candidate is replaced at most once
+    // per change of its validity, so the loop ends (bounded anyway: never spin forever on bad input)
     for (long long guard = 0; merges < n - 1 && guard < (long long)n * n + 1024; ++guard) {
-        // best candidate edge over all nodes: minimum of the fp32 roundings (NaN = no candidate,
-        // ignored by min and never equal), then the nodes that attain it; exact (key, flat index)
-        // comparison only when more than one does
-        int i = -1, hits = 0;
-        float m;
+        // best candidate edge over all nodes: minimum of the group minima, then the nodes that attain
+        // it (fp32 roundings; NaN = no candidate, never equal); exact (key, flat index) comparison
+        // only when more than one node does and they do not simply name each other
         const unsigned long long t0 = prof ? clock64() : 0;
-        if (n <= 128) {
-            scan_small<2>(L, n, lane, m, i, hits);
-        } else if (n <= 256) {
-            scan_small<4>(L, n, lane, m, i, hits);
-        } else if (n <= 512) {
-            scan_small<8>(L, n, lane, m, i, hits);
+        float m;
+        unsigned long long gb0 = 0ull, gb1 = 0ull;
+        int i = -1, second = -1, hits = 0;
+        if (n <= 128) {                                 // small maps: the candidates themselves
+            const float a0 = lane < n ? L.capx[lane] : __builtin_nanf("");
+            const float a1 = lane + 64 < n ? L.capx[lane + 64] : __builtin_nanf("");
+            m = wave_min(fminf(a0, a1));
+            unsigned long long bal = __ballot(a0 == m), bal1 = __ballot(a1 == m);
+            hits = __popcll(bal) + __popcll(bal1);
+            while ((bal | bal1) && second < 0) {
+                int node;
+                if (bal) { node = __ffsll((long long)bal) - 1; bal &= bal - 1; }
+                else { node = 64 + __ffsll((long long)bal1) - 1; bal1 &= bal1 - 1; }
+                if (i < 0) i = node; else second = node;
+            }
         } else {
-            float la = INFINITY;
-            for (int k = lane; k < n; k += 64) la = fminf(la, L.capx[k]);
-            m = wave_min(la);
-            for (int k0 = 0; k0 < n; k0 += 64) {
-                const unsigned long long bal = __ballot(k0 + lane < n && L.capx[k0 + lane] == m);
-                if (bal) { hits += __popcll(bal); i = k0 + __ffsll((long long)bal) - 1; }
+            const float g0v = lane < G ? L.gmin[lane] : INFINITY;
+            const float g1v = lane + 64 < G ? L.gmin[lane + 64] : INFINITY;
+            m = wave_min(fminf(g0v, g1v));
+            gb0 = __ballot(g0v == m);
+            gb1 = __ballot(g1v == m);
+        }
+        while (gb0 | gb1) {                             // groups whose minimum is m (usually one)
+            int g;
+            if (gb0) { g = __ffsll((long long)gb0) - 1; gb0 &= gb0 - 1; }
+            else { g = 64 + __ffsll((long long)gb1) - 1; gb1 &= gb1 - 1; }
+            const int k = (g << 6) + lane;
+            unsigned long long bal = __ballot(k < n && L.capx[k] == m);
+            hits += __popcll(bal);
+            while (bal && second < 0) {
+                const int node = (g << 6) + __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                if (i < 0) i = node; else second = node;
             }
         }
         if (hits == 0) break;                           // no valid edge left (cannot happen for n >= 2)
-        if (hits > 1) {
+        if (hits > 1 && !(hits == 2 && L.cj[i] == second && L.cj[second] == i)) {
+            // different edges with the same fp32 key: exact keys from the key matrix.  (Two nodes that
+            // name each other are one edge with one key; the lower flat index is the lower node = i.)
             double bk = INFINITY;
             unsigned bf = 0xffffffffu;
             for (int k = lane; k < n; k += 64) {
                 if (!(L.capx[k] == m)) continue;
                 const unsigned f = (unsigned)k * (unsigned)n + L.cj[k];
-                if (better(L.ckey[k], f, bk, bf)) { bk = L.ckey[k]; bf = f; }
+                const double key = Kb[f];
+                if (better(key, f, bk, bf)) { bk = key; bf = f; }
             }
             wave_best(bk, bf);
             i = (int)(bf / (unsigned)n);
@@ -262,8 +378,12 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
             }
             ++merges;
             __builtin_amdgcn_wave_barrier();
+            refresh_group(L, n, i, lane);
+            if ((j >> 6) != (i >> 6)) refresh_group(L, n, j, lane);
         } else {
-            rescan(L, Kb, n, i, lane);
+            if (!advance(L, K, i, lane)) rescan<W>(L, Kb, n, i, lane);
+            __builtin_amdgcn_wave_barrier();
+            refresh_group(L, n, i, lane);
         }
         __builtin_amdgcn_wave_barrier();
         if (prof) {
@@ -305,12 +425,21 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
     }
 }
 
-constexpr int kGreedyMaxN = 4500;       // 21 B of LDS per node
+constexpr int kGreedyMaxN = 4500;
 
-inline size_t greedy_lds(int n) { return (size_t)n * (8 + 4 + 2 + 2 + 4 + 1) + 64; }
+// list entries per node (extracted by the prepare kernel and kept in LDS by the merge loop): kTopK
+// while a heat map's state stays near 64 KB; 2 for larger n; 1 (the row's best only) for small n,
+// where tracking and extracting more costs the prepare kernel more than the merge loop gains
+inline int greedy_k(int n) { return n <= 128 ? 1 : n <= 1700 ? kTopK : 2; }
+
+inline size_t greedy_lds(int n)
+{
+    const int K = greedy_k(n);
+    return (size_t)n * (4 + 6 * (size_t)K + 2 + 2 + 4 + 1 + 1) + 128 * 4 + 64;
+}
 
 struct GreedyWs {
-    size_t off_key, off_cj, total;      // key matrices at 0
+    size_t off_lkey, off_lj, total;     // key matrices at 0
 };
 
 inline GreedyWs greedy_ws(int64_t num_maps, int n)
@@ -318,8 +447,8 @@ inline GreedyWs greedy_ws(int64_t num_maps, int n)
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     GreedyWs w{};
     size_t o = up((size_t)num_maps * (size_t)n * (size_t)n * 8);
-    w.off_key = o; o += up((size_t)num_maps * (size_t)n * 8);
-    w.off_cj = o; o += up((size_t)num_maps * (size_t)n * 4);
+    w.off_lkey = o; o += up((size_t)num_maps * (size_t)n * kTopK * 4);
+    w.off_lj = o; o += up((size_t)num_maps * (size_t)n * kTopK * 2);
     w.total = o + 256;
     return w;
 }
@@ -334,19 +463,23 @@ int greedy_t(const void* heat, const double* points, int64_t* tours, int64_t num
     const GreedyWs wl = greedy_ws(num_maps, n);
     unsigned char* w8 = static_cast<unsigned char*>(ws);
     double* Kd = reinterpret_cast<double*>(w8);
-    double* ckey = reinterpret_cast<double*>(w8 + wl.off_key);
-    unsigned* cj = reinterpret_cast<unsigned*>(w8 + wl.off_cj);
+    float* lkey = reinterpret_cast<float*>(w8 + wl.off_lkey);
+    uint16_t* lj = reinterpret_cast<uint16_t*>(w8 + wl.off_lj);
     // grid.y is limited to 65535: prepare in slabs of heat maps
     for (int64_t b0 = 0; b0 < num_maps; b0 += 32768) {
         const dim3 grid((unsigned)((n + 31) / 32), (unsigned)std::min<int64_t>(32768, num_maps - b0), 1);
-        hipLaunchKernelGGL(k_greedy_prepare<H>, grid, dim3(64, 4), 0, stream, A, points, Kd, ckey, cj, n, mpi, b0);
+        if (greedy_k(n) == 1)
+            hipLaunchKernelGGL((k_greedy_prepare<H, 1>), grid, dim3(64, 8), 0, stream, A, points, Kd, lkey, lj, n, mpi, b0, 1);
+        else
+            hipLaunchKernelGGL((k_greedy_prepare<H, 2>), grid, dim3(64, 8), 0, stream, A, points, Kd, lkey, lj, n, mpi, b0, greedy_k(n));
         HIP_TRY(hipGetLastError());
     }
     const size_t lds = greedy_lds(n);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy),
+    auto kern = n <= 512 ? k_greedy<8> : k_greedy<16>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_greedy, dim3((unsigned)num_maps), dim3(64), lds, stream, Kd, ckey, cj, tours,
-                       num_maps, n, g_greedy_prof_on);
+    hipLaunchKernelGGL(kern, dim3((unsigned)num_maps), dim3(64), lds, stream, Kd, lkey, lj, tours,
+                       num_maps, n, greedy_k(n), g_greedy_prof_on);
     HIP_TRY(hipGetLastError());
     return 0;
 }
