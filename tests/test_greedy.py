@@ -62,7 +62,10 @@ def test_gpu_greedy_matches_reference_golden(path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,inst,mpi,dtype", [(7, 3, 2, np.float32), (33, 5, 3, np.float64),
                                              (100, 16, 4, np.float32), (257, 3, 2, np.float32),
-                                             (1000, 2, 1, np.float32)])
+                                             (1000, 2, 1, np.float32),
+                                             # list lengths 1 / 4 / 2 and both rescan widths
+                                             (128, 3, 2, np.float32), (130, 4, 2, np.float64),
+                                             (513, 2, 1, np.float32), (1800, 1, 1, np.float32)])
 def test_gpu_greedy_matches_oracle_random(n, inst, mpi, dtype):
     from ml4tspbench_amd import greedy_decode_device, two_opt_device, evaluate_tours
     from oracle import greedy_oracle
