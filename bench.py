@@ -146,15 +146,17 @@ def main():
     d_tours = torch.from_numpy(tours).to(dev)
     gather_t = gather_l = None
     if use_dist:
-        gather_t = torch.empty((world * T, n + 1), dtype=torch.int64, device=dev)
+        from ml4tspbench_amd.sharding import pack_tours, unpack_tours
+        gather_t = torch.empty((world * T, pack_tours(d_tours[:1]).shape[1]), dtype=torch.uint8, device=dev)
         gather_l = torch.empty(world * T, dtype=torch.float64, device=dev)
 
     def step():
         res = amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi, group_size=group,
                                  max_iterations=args.max_iterations, want_lengths=True)
-        if use_dist:        # the only exchange of the path: final gather of tours and lengths
-            dist.all_gather_into_tensor(gather_t, res.tours)
+        if use_dist:        # the only exchange of the path: final gather of tours (as int16) and lengths
+            dist.all_gather_into_tensor(gather_t, pack_tours(res.tours))
             dist.all_gather_into_tensor(gather_l, res.lengths)
+            res.all_tours = unpack_tours(gather_t, n + 1)      # (world * T, N+1) int64 on every rank
         return res
 
     def fence():
@@ -182,6 +184,8 @@ def main():
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
         dt = float(tdt.item())
 
+    if use_dist:            # the gathered copy holds this rank's tours at its own offset
+        assert torch.equal(res.all_tours[rank * T:(rank + 1) * T], res.tours), "final gather corrupted the tours"
     sweeps = res.sweeps.to(torch.int64)
     iters = res.iterations
     my_pd = torch.tensor([float(sweeps.sum().item()) * pairs, float(T), float(iters.sum().item()),

@@ -74,4 +74,26 @@ def solve_sharded(points: torch.Tensor, tours: torch.Tensor, *, tours_per_instan
                  for r, (a, b) in enumerate(blocks)]
         return torch.cat(parts, dim=0)
 
-    return gather(res.tours.to(dev)), gather(res.iterations.to(dev)), gather(res.lengths.to(dev))
+    return (gather_tours(res.tours.to(dev), gather), gather(res.iterations.to(dev)),
+            gather(res.lengths.to(dev)))
+
+
+def pack_tours(tours: torch.Tensor) -> torch.Tensor:
+    """(T, N+1) int64 node indices -> the bytes that travel in the final gather: int16 when every
+    index fits (N <= 32767; a quarter of the int64 volume), as a uint8 view so that any backend's
+    all_gather takes it."""
+    dt = torch.int16 if tours.shape[1] - 1 <= 32767 else torch.int64
+    packed = torch.empty(tuple(tours.shape), dtype=dt, device=tours.device)    # fresh, contiguous strides
+    packed.copy_(tours)
+    return packed.view(torch.uint8)
+
+
+def unpack_tours(packed: torch.Tensor, n1: int) -> torch.Tensor:
+    """Inverse of pack_tours for tours of n1 = N+1 entries."""
+    if n1 - 1 <= 32767:
+        return packed.view(torch.int16).to(torch.int64)
+    return packed.view(torch.int64)
+
+
+def gather_tours(tours: torch.Tensor, gather: Callable) -> torch.Tensor:
+    return unpack_tours(gather(pack_tours(tours)), tours.shape[1])
