@@ -90,6 +90,11 @@ def cpu_baseline(name: str, pts: np.ndarray, tours: np.ndarray, tpi: int, group:
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON: everything else that libraries print there (RCCL's
+    # version banner at communicator creation, for one) is sent to stderr until the line is due
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -262,7 +267,10 @@ def main():
             cb["gpu_matches_oracle_on_sample"] = same
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
