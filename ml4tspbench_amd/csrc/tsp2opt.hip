@@ -560,10 +560,13 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& u
         if (pf.on) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
         const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
         const float wm = wave_min(a1);
-        if (lane == 0) ctl->wmin[wv] = wm;
-        __syncthreads();
-        float m = ctl->wmin[0];
-        for (int w = 1; w < nw; ++w) m = fminf(m, ctl->wmin[w]);
+        float m = wm;
+        if (nw > 1) {                                       // one-wave workgroups need no LDS round trip
+            if (lane == 0) ctl->wmin[wv] = wm;
+            __syncthreads();
+            m = ctl->wmin[0];
+            for (int w = 1; w < nw; ++w) m = fminf(m, ctl->wmin[w]);
+        }
         float thr = m + g.eps2;
         if constexpr (CL) {
             // This workgroup sees only its own tiles, whose minimum may be far above the tour's.  Only
@@ -632,16 +635,21 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& u
             unsigned widx = 0xffffffffu;
             if (hm) widx = (unsigned)__builtin_amdgcn_readlane((int)fidx, __ffsll((long long)hm) - 1);
             const bool wother = __ballot(multi || (fidx != 0xffffffffu && fidx != widx)) != 0ull;
-            if (lane == 0) {
-                ctl->pE[wv] = wd;
-                ctl->pIdx[wv] = widx;
-                ctl->pAmb[wv] = amb | (wother ? 2 : 0);
-            }
-            __syncthreads();
-            double bd = ctl->pE[0];
-            unsigned bi = ctl->pIdx[0];
-            int fl = ctl->pAmb[0];
+            double bd = wd;
+            unsigned bi = widx;
+            int fl = amb | (wother ? 2 : 0);
             bool unique = true;
+            if (nw > 1) {
+                if (lane == 0) {
+                    ctl->pE[wv] = wd;
+                    ctl->pIdx[wv] = widx;
+                    ctl->pAmb[wv] = fl;
+                }
+                __syncthreads();
+                bd = ctl->pE[0];
+                bi = ctl->pIdx[0];
+                fl = ctl->pAmb[0];
+            }
             for (int w = 1; w < nw; ++w) {
                 const double od = ctl->pE[w];
                 const unsigned oi = ctl->pIdx[w];
