@@ -124,10 +124,11 @@ __global__ void __launch_bounds__(512) k_greedy_prepare(const H* __restrict__ A,
         b1k[rr] = b2k[rr] = INFINITY;
         b1j[rr] = b2j[rr] = 0xffffu;
     }
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        // both operands' global loads are issued before the barrier: one round trip per tile
+    // software pipeline: the global loads of tile c0 + 64 (both operands) are in flight while tile c0
+    // is computed
+    H a[4], tr[4];
+    auto load_tile = [&](int c0) {
         const int j = c0 + x;
-        H a[4], tr[4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int i = i0 + y + 8 * rr;
@@ -139,17 +140,25 @@ __global__ void __launch_bounds__(512) k_greedy_prepare(const H* __restrict__ A,
             const int jr = c0 + c, ic = i0 + r;
             tr[k] = (jr < n && ic < n) ? Ab[(size_t)jr * n + ic] : (H)0;
         }
+    };
+    load_tile(0);
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int j = c0 + x;
         const double cx = j < n ? P[2 * j] : 0.0, cy = j < n ? P[2 * j + 1] : 0.0;
+        H ac[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) ac[rr] = a[rr];
 #pragma unroll
         for (int k = 0; k < 4; ++k) tile[(t >> 5) + 16 * k][t & 31] = tr[k];
         __syncthreads();
+        if (c0 + 64 < n) load_tile(c0 + 64);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int r = y + 8 * rr, i = i0 + r;
             if (i < n && j < n) {
                 double k = INFINITY;
                 if (j != i) {
-                    const H s = a[rr] + tile[x][r];
+                    const H s = ac[rr] + tile[x][r];
                     const double dx = rx[rr] - cx, dy = ry[rr] - cy;
                     k = -(double)s / sqrt(dx * dx + dy * dy);
                     k = k != k ? INFINITY : k;
