@@ -193,26 +193,31 @@ __global__ void __launch_bounds__(512) k_greedy_prepare(const H* __restrict__ A,
 // [3] merges, [4] rescans, [5] total cycles of the merge loop, summed over heat maps (lane 0)
 __device__ unsigned long long g_greedy_prof[8];
 
+struct Cand {               // node i's candidate edge i -> cj, one 8-byte LDS read
+    float key;              // fp32 rounding of its key; NaN = the node has no candidate (interior / none left)
+    unsigned cj;            // partner
+};
+
 struct GreedyLds {          // carve of the dynamic LDS for one heat map (one wave)
-    float* capx;            // fp32 rounding of the key of node i's candidate edge i -> cj[i]; NaN = none
-    float* gmin;            // minimum of capx over every group of 64 nodes (+inf: no candidate in the group)
+    Cand* cand;
     float* lk;              // K list entries per node: fp32 key (NaN = none) ...
     uint16_t* lj;           // ... and partner (0xffff = none), exact (key, j) order
-    uint16_t* cj;           // candidate partner
     uint16_t* oend;         // for a fragment endpoint: the fragment's other endpoint (itself if alone)
     uint16_t* nb;           // 2 neighbour slots per node, 0xffff = empty
     uint8_t* deg;
     uint8_t* lp;            // cursor into the node's list (K: list used up, candidates come from rescans)
 };
 
-// refresh the minimum of node x's group after capx[x] changed (all 64 lanes)
-__device__ __forceinline__ void refresh_group(const GreedyLds& L, int n, int x, int lane)
+// The minimum candidate key of every group of 64 nodes lives in registers: lane l holds groups l
+// (gm0) and l + 64 (gm1); +inf = no candidate in the group.  Refresh the minimum of node x's group
+// after its candidate changed (all 64 lanes).
+__device__ __forceinline__ void refresh_group(const GreedyLds& L, int n, int x, int lane, float& gm0, float& gm1)
 {
     if (n <= 128) return;                               // two groups at most: scanned directly
     const int g = x >> 6, k = (g << 6) + lane;
-    const float v = k < n ? L.capx[k] : __builtin_nanf("");
+    const float v = k < n ? L.cand[k].key : __builtin_nanf("");
     const float m = wave_min(v != v ? INFINITY : v);
-    if (lane == 0) L.gmin[g] = m;
+    if (lane == (g & 63)) { if (g < 64) gm0 = m; else gm1 = m; }
 }
 
 // can node i still take partner j?  (j is a fragment endpoint of another fragment)
@@ -244,10 +249,7 @@ __device__ __forceinline__ void rescan(const GreedyLds& L, const double* __restr
         }
     }
     wave_best(bk, bj);
-    if (lane == 0) {
-        L.cj[i] = (uint16_t)bj;
-        L.capx[i] = bj == 0xffffu ? __builtin_nanf("") : (float)bk;
-    }
+    if (lane == 0) L.cand[i] = Cand{bj == 0xffffu ? __builtin_nanf("") : (float)bk, bj};
 }
 
 // node i's candidate is no longer valid: the next valid entry of its list, else a rescan
@@ -264,8 +266,7 @@ __device__ __forceinline__ bool advance(const GreedyLds& L, int K, int i, int la
     const int p = __ffsll((long long)bal) - 1;
     if (lane == 0) {
         L.lp[i] = (uint8_t)p;
-        L.cj[i] = L.lj[i * K + p];
-        L.capx[i] = L.lk[i * K + p];
+        L.cand[i] = Cand{L.lk[i * K + p], L.lj[i * K + p]};
     }
     return true;
 }
@@ -283,11 +284,9 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
     const int G = (n + 63) >> 6;                        // groups of 64 nodes, <= 128
     GreedyLds L;
     size_t off = 0;
-    L.capx = reinterpret_cast<float*>(smem + off); off += sizeof(float) * (size_t)n;
-    L.gmin = reinterpret_cast<float*>(smem + off); off += sizeof(float) * 128;
+    L.cand = reinterpret_cast<Cand*>(smem + off); off += sizeof(Cand) * (size_t)n;
     L.lk = reinterpret_cast<float*>(smem + off); off += sizeof(float) * (size_t)n * K;
     L.lj = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n * K;
-    L.cj = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n;
     L.oend = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n;
     L.nb = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * 2 * (size_t)n;
     L.deg = reinterpret_cast<uint8_t*>(smem + off); off += (size_t)n;
@@ -303,11 +302,11 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
             L.lk[i * K + p] = lkey[src + p];
             L.lj[i * K + p] = lj0[src + p];
         }
-        L.capx[i] = lkey[src];                          // first candidates: the heads of the lists
-        L.cj[i] = lj0[src];
+        L.cand[i] = Cand{lkey[src], lj0[src]};          // first candidates: the heads of the lists
     }
     __builtin_amdgcn_wave_barrier();
-    for (int g = 0; g < G; ++g) refresh_group(L, n, g << 6, lane);
+    float gm0 = INFINITY, gm1 = INFINITY;
+    for (int g = 0; g < G; ++g) refresh_group(L, n, g << 6, lane, gm0, gm1);
     __builtin_amdgcn_wave_barrier();
 
     int merges = 0;
@@ -322,54 +321,56 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
         float m;
         unsigned long long gb0 = 0ull, gb1 = 0ull;
         int i = -1, second = -1, hits = 0;
-        if (n <= 128) {                                 // small maps: the candidates themselves
-            const float a0 = lane < n ? L.capx[lane] : __builtin_nanf("");
-            const float a1 = lane + 64 < n ? L.capx[lane + 64] : __builtin_nanf("");
-            m = wave_min(fminf(a0, a1));
-            unsigned long long bal = __ballot(a0 == m), bal1 = __ballot(a1 == m);
-            hits = __popcll(bal) + __popcll(bal1);
-            while ((bal | bal1) && second < 0) {
-                int node;
-                if (bal) { node = __ffsll((long long)bal) - 1; bal &= bal - 1; }
-                else { node = 64 + __ffsll((long long)bal1) - 1; bal1 &= bal1 - 1; }
-                if (i < 0) i = node; else second = node;
+        unsigned cji = 0, cjs = 0;                      // partners of i and second
+        auto take = [&](unsigned long long bal, int base, unsigned cjl) {
+            while (bal && second < 0) {
+                const int src = __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)cjl, src);
+                if (i < 0) { i = base + src; cji = c; } else { second = base + src; cjs = c; }
             }
+        };
+        if (n <= 128) {                                 // small maps: the candidates themselves
+            const Cand c0 = lane < n ? L.cand[lane] : Cand{__builtin_nanf(""), 0u};
+            const Cand c1 = lane + 64 < n ? L.cand[lane + 64] : Cand{__builtin_nanf(""), 0u};
+            m = wave_min(fminf(c0.key, c1.key));
+            const unsigned long long bal = __ballot(c0.key == m), bal1 = __ballot(c1.key == m);
+            hits = __popcll(bal) + __popcll(bal1);
+            take(bal, 0, c0.cj);
+            take(bal1, 64, c1.cj);
         } else {
-            const float g0v = lane < G ? L.gmin[lane] : INFINITY;
-            const float g1v = lane + 64 < G ? L.gmin[lane + 64] : INFINITY;
-            m = wave_min(fminf(g0v, g1v));
-            gb0 = __ballot(g0v == m);
-            gb1 = __ballot(g1v == m);
+            m = wave_min(fminf(gm0, gm1));
+            gb0 = __ballot(gm0 == m);
+            gb1 = __ballot(gm1 == m);
         }
         while (gb0 | gb1) {                             // groups whose minimum is m (usually one)
             int g;
             if (gb0) { g = __ffsll((long long)gb0) - 1; gb0 &= gb0 - 1; }
             else { g = 64 + __ffsll((long long)gb1) - 1; gb1 &= gb1 - 1; }
             const int k = (g << 6) + lane;
-            unsigned long long bal = __ballot(k < n && L.capx[k] == m);
+            const Cand c = k < n ? L.cand[k] : Cand{__builtin_nanf(""), 0u};
+            const unsigned long long bal = __ballot(c.key == m);
             hits += __popcll(bal);
-            while (bal && second < 0) {
-                const int node = (g << 6) + __ffsll((long long)bal) - 1;
-                bal &= bal - 1;
-                if (i < 0) i = node; else second = node;
-            }
+            take(bal, g << 6, c.cj);
         }
         if (hits == 0) break;                           // no valid edge left (cannot happen for n >= 2)
-        if (hits > 1 && !(hits == 2 && L.cj[i] == second && L.cj[second] == i)) {
+        if (hits > 1 && !(hits == 2 && cji == (unsigned)second && cjs == (unsigned)i)) {
             // different edges with the same fp32 key: exact keys from the key matrix.  (Two nodes that
             // name each other are one edge with one key; the lower flat index is the lower node = i.)
             double bk = INFINITY;
             unsigned bf = 0xffffffffu;
             for (int k = lane; k < n; k += 64) {
-                if (!(L.capx[k] == m)) continue;
-                const unsigned f = (unsigned)k * (unsigned)n + L.cj[k];
+                const Cand c = L.cand[k];
+                if (!(c.key == m)) continue;
+                const unsigned f = (unsigned)k * (unsigned)n + c.cj;
                 const double key = Kb[f];
                 if (better(key, f, bk, bf)) { bk = key; bf = f; }
             }
             wave_best(bk, bf);
             i = (int)(bf / (unsigned)n);
+            cji = bf - (unsigned)i * (unsigned)n;
         }
-        const int j = L.cj[i];
+        const int j = (int)cji;
         const int oi = L.oend[i], oj = L.oend[j];
         const bool valid = L.deg[j] < 2 && !(oi == j && oi != i);
         const unsigned long long t1 = prof ? clock64() : 0;
@@ -380,19 +381,19 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
                 const int di = L.deg[i] + 1, dj = L.deg[j] + 1;
                 L.deg[i] = (uint8_t)di;
                 L.deg[j] = (uint8_t)dj;
-                if (di >= 2) L.capx[i] = __builtin_nanf("");
-                if (dj >= 2) L.capx[j] = __builtin_nanf("");
+                if (di >= 2) L.cand[i].key = __builtin_nanf("");
+                if (dj >= 2) L.cand[j].key = __builtin_nanf("");
                 L.oend[oi] = (uint16_t)oj;      // the merged fragment runs from oi to oj
                 L.oend[oj] = (uint16_t)oi;
             }
             ++merges;
             __builtin_amdgcn_wave_barrier();
-            refresh_group(L, n, i, lane);
-            if ((j >> 6) != (i >> 6)) refresh_group(L, n, j, lane);
+            refresh_group(L, n, i, lane, gm0, gm1);
+            if ((j >> 6) != (i >> 6)) refresh_group(L, n, j, lane, gm0, gm1);
         } else {
             if (!advance(L, K, i, lane)) rescan<W>(L, Kb, n, i, lane);
             __builtin_amdgcn_wave_barrier();
-            refresh_group(L, n, i, lane);
+            refresh_group(L, n, i, lane, gm0, gm1);
         }
         __builtin_amdgcn_wave_barrier();
         if (prof) {
@@ -444,7 +445,7 @@ inline int greedy_k(int n) { return n <= 128 ? 1 : n <= 1700 ? kTopK : 2; }
 inline size_t greedy_lds(int n)
 {
     const int K = greedy_k(n);
-    return (size_t)n * (4 + 6 * (size_t)K + 2 + 2 + 4 + 1 + 1) + 128 * 4 + 64;
+    return (size_t)n * (8 + 6 * (size_t)K + 2 + 4 + 1 + 1) + 64;
 }
 
 struct GreedyWs {
