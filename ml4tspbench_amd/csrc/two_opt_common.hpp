@@ -1,0 +1,210 @@
+// ml4tspbench_amd/csrc/two_opt_common.hpp -- constants, parameter blocks, LDS view, exact arithmetic of the 2-opt kernels
+// Part of the single translation unit tsp2opt.hip (design notes at its top and in DESIGN.md).
+#pragma once
+
+namespace t2o {
+
+// ------------------------------------------------------------------------------------------
+// constants shared by host and device
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxCand = 64;          // exact re-evaluation list (macro steps) per iteration
+constexpr int kMaxWaves = 16;         // 1024 threads
+constexpr int kModeIndep = 0;         // run from iteration 0 until the tour's own stop test
+constexpr int kModeForced = 1;        // continue to the group's iteration count (coupled mode)
+constexpr unsigned kNoMove = 0u;      // packed (i<<16|j) == 0 <=> flat argmin index 0 <=> no move
+constexpr unsigned kFullSweep = 0xffffffffu;   // "last move" value that asks for a full filter sweep
+
+struct Geo {                          // launch geometry of the filter sweep (host: make_plan)
+    int n;                            // nodes
+    int nt;                           // threads per workgroup
+    int qclass;                       // 0: exact-only kernel; else sub-array stride Q
+    int GP;                           // lane groups; group gp owns cyclic diagonals 2+8gp .. 9+8gp
+    int CS, wc;                       // workgroups sharing the tour (1 = none) and this workgroup's index
+    int GPl;                          // lane groups walked by this workgroup: gp = wc + CS*gpl, gpl < GPl
+    int G;                            // = 2 * GP groups of 4 diagonals (cyclic diagonals 2..4G+1)
+    int NS;                           // row segments
+    int MS;                           // macro steps (4 rows) per segment, even: MS/2 tiles of 8 rows
+    int xlds;                         // exact coordinates cached in LDS
+    int W;                            // window entries kept consistent (multiple of 8, <= 8*Q)
+    int inc;                          // tile-minimum cache + incremental sweeps
+    int lcap;                         // capacity of the changed-tile list
+    float eps2;                       // 2*eps of the filter, in scaled units
+};
+
+struct Params {
+    const void* points;
+    int64_t* tours;
+    int32_t* iters;                   // INDEP: out.  FORCED: in (own count) / unchanged
+    int32_t* work_sweeps;             // sweeps actually executed (accumulated)
+    int32_t* status;
+    const int32_t* target;            // FORCED: per-group iteration count
+    int32_t* group_flag;              // FORCED: set when a tour is still active at the target
+    unsigned* queue;                  // tour queue head
+    int64_t num_tours;
+    int tpi;
+    int group_size;
+    int max_iter;
+    int mode;
+    long long time_limit_ticks;       // wall_clock64 ticks, 0 = none
+    unsigned long long* stamps;       // optional phase timers (tsp2opt_debug_phase_cycles), else null
+    int dbg_sweeps;                   // > 0: diagnostic, run only this many filter sweeps per tour
+    unsigned* csync;                  // CS > 1: per cluster `cstride` dwords: [0] arrivals, [1] abort, [16..] slots
+    int cstride;
+    int num_clusters;
+    Geo g;
+};
+
+struct Prof {                         // per-thread phase timers, only live when Params::stamps != null
+    bool on;
+    unsigned long long sweep, select, apply;
+    unsigned amb = 0, cands = 0;
+    unsigned long long candcyc = 0;
+#ifdef TSP2OPT_FINE
+    unsigned long long tl = 0, fine[16] = {};
+#endif
+};
+
+// Diagnostic build only (-DTSP2OPT_FINE, libtsp2opt_hip_fine.so): FINE(pf, k) charges the shader-clock
+// cycles since the previous mark to slot k; the slots are summed into workspace stamps [8, 24).
+#ifdef TSP2OPT_FINE
+#define FINE_START(pf) do { if ((pf).on) (pf).tl = clock64(); } while (0)
+#define FINE(pf, k) do { if ((pf).on) { const unsigned long long t_ = clock64(); (pf).fine[k] += t_ - (pf).tl; (pf).tl = t_; } } while (0)
+#else
+#define FINE_START(pf) do { } while (0)
+#define FINE(pf, k) do { } while (0)
+#endif
+
+struct Ctl {                          // LDS control block (first bytes of dynamic LDS)
+    double redd[kMaxWaves * 4];       // block reductions
+    double pE[kMaxWaves];
+    unsigned pIdx[kMaxWaves];
+    float wmin[kMaxWaves];
+    int pAmb[kMaxWaves];
+    unsigned cand[kMaxCand];
+    unsigned nlist;                   // changed tiles queued for this iteration
+    int ambiguous;
+    int tour_id;
+    int flags;
+    double bestE;
+    unsigned bestIdx;
+    unsigned pad;
+    double cx, cy, sc;
+};
+
+// ------------------------------------------------------------------------------------------
+// exact arithmetic in the reference's dtype (search/two_opt.py:27-32): separate sub, mul, add,
+// correctly rounded sqrt.  fp32 sqrt goes through the correctly rounded fp64 sqrt: rounding a
+// 53-bit correctly rounded root of a 24-bit value to 24 bits is itself correctly rounded.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sqrt_rn(double x) { return __builtin_sqrt(x); }
+__device__ __forceinline__ float sqrt_rn(float x) { return (float)__builtin_sqrt((double)x); }
+
+template <typename T>
+__device__ __forceinline__ T dist_exact(T ax, T ay, T bx, T by)
+{
+    T dx = ax - bx, dy = ay - by;
+    T sx = dx * dx;
+    T sy = dy * dy;
+    return sqrt_rn(sx + sy);
+}
+
+// fp32 filter distance: FMA and the raw 1-ulp v_sqrt_f32 are fine here, the error is budgeted.
+__device__ __forceinline__ float dist32(float ax, float ay, float bx, float by)
+{
+    float dx = ax - bx, dy = ay - by;
+    return __builtin_amdgcn_sqrtf(__builtin_fmaf(dy, dy, dx * dx));
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));   // (stream A, stream B)
+
+__device__ __forceinline__ v2f dist32x2(float ax, float ay, v2f bx, v2f by)
+{
+    const v2f dx = (v2f){ax, ax} - bx, dy = (v2f){ay, ay} - by;
+    const v2f s = __builtin_elementwise_fma(dy, dy, dx * dx);
+    return (v2f){__builtin_amdgcn_sqrtf(s.x), __builtin_amdgcn_sqrtf(s.y)};
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS view of one tour
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct View {
+    Ctl* ctl;
+    uint16_t* tour;        // n+1 positions
+    // filter copy, 8*Q entries each; slot(w) = (w&7)*Q + (w>>3), w = window (cyclic position) index;
+    // entry slot(w) = (value at w, value at w + 4): the two streams of a lane in one 8-byte read
+    v2f* Xq;               // x
+    v2f* Yq;               // y
+    v2f* Eq;               // edge lengths e[w] = |P[w] P[w+1]|
+    float* Mc;             // filter minimum of every tile (8 rows x 8 diagonals), or null
+    uint16_t* list;        // ids of the tiles the last reversal touched
+    const T* X;            // exact coordinates, node order (LDS copy or global)
+};
+
+template <int Q>
+__device__ __forceinline__ int slot(int w) { return (w & 7) * Q + (w >> 3); }
+
+// exact delta of position pair (i, j), i + 2 <= j <= n-1, in the reference's operation order
+template <typename T>
+__device__ __forceinline__ double exact_delta(const View<T>& v, int i, int j)
+{
+    const int ti = v.tour[i], ti1 = v.tour[i + 1], tj = v.tour[j], tj1 = v.tour[j + 1];
+    const T xi = v.X[2 * ti], yi = v.X[2 * ti + 1];
+    const T xi1 = v.X[2 * ti1], yi1 = v.X[2 * ti1 + 1];
+    const T xj = v.X[2 * tj], yj = v.X[2 * tj + 1];
+    const T xj1 = v.X[2 * tj1], yj1 = v.X[2 * tj1 + 1];
+    const T a_ij = dist_exact(xi, yi, xj, yj);
+    const T a_i1j1 = dist_exact(xi1, yi1, xj1, yj1);
+    const T a_ii1 = dist_exact(xi, yi, xi1, yi1);
+    const T a_jj1 = dist_exact(xj, yj, xj1, yj1);
+    const T d = ((a_ij + a_i1j1) - a_ii1) - a_jj1;      // two_opt.py:32, left to right
+    return (double)d;
+}
+
+// Full exact sweep by the whole workgroup (fallback of the filter, and the only sweep of the
+// exact-only kernel).  Thread-local scan order is ascending (i, j), so strict '<' keeps the
+// lowest flat index; the cross-thread reduction is lexicographic on (delta, index).
+template <typename T>
+__device__ void exact_sweep(const View<T>& v, int n, int tid, int nt, double& e, unsigned& idx)
+{
+    e = 0.0;
+    idx = kNoMove;
+    for (int i = tid; i + 2 <= n - 1; i += nt) {
+        const int ti = v.tour[i], ti1 = v.tour[i + 1];
+        const T xi = v.X[2 * ti], yi = v.X[2 * ti + 1];
+        const T xi1 = v.X[2 * ti1], yi1 = v.X[2 * ti1 + 1];
+        const T a_ii1 = dist_exact(xi, yi, xi1, yi1);
+        int tj = v.tour[i + 2];
+        T xj = v.X[2 * tj], yj = v.X[2 * tj + 1];
+        for (int j = i + 2; j <= n - 1; ++j) {
+            const int tj1 = v.tour[j + 1];
+            const T xj1 = v.X[2 * tj1], yj1 = v.X[2 * tj1 + 1];
+            const T a_ij = dist_exact(xi, yi, xj, yj);
+            const T a_i1j1 = dist_exact(xi1, yi1, xj1, yj1);
+            const T a_jj1 = dist_exact(xj, yj, xj1, yj1);
+            const double d = (double)(((a_ij + a_i1j1) - a_ii1) - a_jj1);
+            if (d < e) { e = d; idx = ((unsigned)i << 16) | (unsigned)j; }
+            xj = xj1; yj = yj1;
+        }
+    }
+}
+
+// workgroup-wide lexicographic min of (e, idx); result valid in every thread
+__device__ void block_best(Ctl* ctl, int tid, int nt, double& e, unsigned& idx)
+{
+    wave_best(e, idx);
+    const int nw = nt >> 6;
+    if (nw == 1) return;
+    if ((tid & 63) == 0) { ctl->pE[tid >> 6] = e; ctl->pIdx[tid >> 6] = idx; }
+    __syncthreads();
+    e = ctl->pE[0];
+    idx = ctl->pIdx[0];
+    for (int w = 1; w < nw; ++w) {
+        const double oe = ctl->pE[w];
+        const unsigned oi = ctl->pIdx[w];
+        if (better(oe, oi, e, idx)) { e = oe; idx = oi; }
+    }
+    __syncthreads();
+}
+
+}  // namespace t2o
