@@ -222,3 +222,31 @@ def test_gpu_cluster_time_limit(amd):
         assert (st & _lib.ST_TIME).all() and (res.iterations.cpu().numpy() < 800).all()
         out = res.tours.cpu().numpy()
         assert (np.sort(out[:, :-1], axis=1) == np.arange(1200)).all()
+
+
+@pytest.mark.parametrize("side,dtype", [(20, np.float64), (23, np.float64), (20, np.float32)])
+def test_gpu_tie_heavy_grids_all_kernels(amd, oracle, side, dtype):
+    """Regular grids: thousands of exactly tied deltas, so nearly every iteration takes the ambiguous
+    path (candidates from the tile cache, list overflow -> exact sweep).  Same tours from the
+    one-workgroup kernel, the full-window cluster and the band cluster as from the oracle."""
+    from ml4tspbench_amd import _lib
+    L = _lib.lib()
+    n = side * side
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"), -1).reshape(n, 2)
+    pts = (g / float(side - 1)).astype(dtype)[None]
+    rng = np.random.default_rng(500 + side)
+    tours = np.zeros((2, n + 1), dtype=np.int64)
+    for k in range(2):
+        tours[k, 1:n] = rng.permutation(np.arange(1, n))
+    ref_out, ref_it, ref_sw = oracle.solve(pts, tours, tours_per_instance=2, max_iterations=5000, threads=2)
+    for mode, variant in ((0, 0), (4, 2), (4, 1)):
+        L.tsp2opt_debug_cluster_mode(mode)
+        L.tsp2opt_debug_tune(3, variant)
+        try:
+            out, iters, sweeps, _, status = _run(amd, pts, tours, 2, 1, 5000)
+        finally:
+            L.tsp2opt_debug_cluster_mode(-1)
+            L.tsp2opt_debug_tune(3, 0)
+        assert (status & (15 | 64)).max(initial=0) == 0, (mode, variant)
+        assert np.array_equal(out, ref_out), (mode, variant)
+        assert np.array_equal(iters, ref_it) and np.array_equal(sweeps, ref_sw), (mode, variant)
