@@ -11,22 +11,33 @@
 // evaluated in the reference's dtype with IEEE-correct +,-,*,sqrt and no FMA, ties broken by the
 // lowest flat index i*N+j, then reverse tour[i+1..j].
 //
-// Hot loop ("filter sweep"): the pair triangle is re-indexed as CYCLIC DIAGONALS (r, (r+d) mod N),
-// d = 2..N/2, which is a rectangle (no triangle waste) and along which D(r+1,c+1) of one pair is
-// D(r,c) of the next, so each pair costs ONE distance.  A lane owns two groups of 4 adjacent
-// diagonals ("streams" A and B, GP groups apart) and walks rows in macro steps of 4 (32 pairs,
-// 32 sqrt).  Every value of the step is an (A, B) register pair, so the subtractions, squares and
-// sums issue as v_pk_add/v_pk_mul/v_pk_fma_f32 (measured on MI355X: 25 SIMD-cycles per 64 pairs
-// against 37 for the scalar form, tools/valu_chain_microbench.hip).  Tour-ordered, centred and
-// scaled fp32 coordinates sit in LDS as three 4-way interleaved arrays (x, y, edge length) whose
-// entries are already the (A, B) pairs: entry i holds the value of window group i and of group
-// i+GP, so one conflict-free ds_read_b64 per operand feeds the packed math with no register moves;
-// row operands are broadcast reads of the same arrays.  The fp32 value is only a FILTER with a proven error bound eps: every lane keeps
-// its best macro-step a1 and runner-up a2; after a workgroup min m, only macro steps with
-// a1 <= m + 2 eps can hold the true argmin and are re-evaluated EXACTLY (reference dtype, reference
-// operation order) by wave 0; if some lane's runner-up is also inside the window the workgroup
-// falls back to a full exact sweep for that iteration.  The result is bit-identical to evaluating
-// every pair exactly, at fp32 VALU cost.
+// Hot loop ("filter sweep", two_opt_kernel.hpp): the pair triangle is re-indexed as CYCLIC DIAGONALS
+// (r, (r+d) mod N), d = 2..N/2, which is a rectangle (no triangle waste) and along which
+// D(r+1,c+1) of one pair is D(r,c) of the next, so each pair costs ONE distance.  A lane owns 8
+// adjacent diagonals as two "streams" A and B of 4 and walks rows in macro steps of 4 (32 pairs,
+// 32 sqrt); two macro steps make a TILE of 8 rows x 8 diagonals.  Every value of a step is an
+// (A, B) register pair, so the subtractions, squares and sums issue as v_pk_add/v_pk_mul/v_pk_fma_f32
+// (measured on MI355X: 25 SIMD-cycles per 64 pairs against 37 for the scalar form,
+// tools/valu_chain_microbench.hip).  Tour-ordered, centred and scaled fp32 coordinates sit in LDS as
+// three 8-way interleaved arrays (x, y, edge length) whose entries are already the (A, B) pairs
+// (value at window position w and at w + 4), so one conflict-free ds_read_b64 per operand feeds the
+// packed math with no register moves; row operands are broadcast reads of the same arrays.
+//
+// The fp32 value is only a FILTER with a proven error bound eps: every lane keeps its best tile a1
+// and runner-up a2; after a workgroup min m only tiles with a1 <= m + 2 eps can hold the true argmin.
+// Those are re-evaluated pair by pair, first in fp32 (a unique in-window pair far enough below
+// -1e-6 IS the argmin: no exact arithmetic), else EXACTLY (reference dtype, reference operation
+// order).  The result is bit-identical to evaluating every pair exactly, at fp32 VALU cost.
+//
+// INCREMENTAL SWEEPS: the filter minimum of every tile is cached in LDS; a reversal of
+// tour[i+1..j] only changes tiles that read a position in [i, j], which every lane marks in closed
+// form; the marked tiles are compacted into a list and recomputed evenly by all lanes (about 42 % of
+// the pairs per iteration at TSP-500).  The cache also names the candidates of iterations where the
+// per-lane best/runner-up is not enough (two candidates in one lane).
+//
+// Few tours: a tour is shared by several workgroups -- the full-window cluster (k_two_opt<.., CL>,
+// lane groups interleaved over the workgroups, N within the fast path) or the band cluster
+// (two_opt_band.hpp, any N) -- which exchange their exact local bests once per iteration.
 //
 // MFMA is deliberately not used: gather + sqrt + compare work, no dense contraction.
 //
