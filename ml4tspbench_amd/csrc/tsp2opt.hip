@@ -155,7 +155,7 @@ Plan make_plan(int n, int dtype, int cs = 1)
                 const size_t tiles = (size_t)GPl * NS * (MS / 2);
                 const size_t lcap = tiles * (size_t)g_lcap16s / 16 + 1;
                 const size_t need = align16(4 * tiles) + align16(2 * lcap);
-                if (MS / 2 >= g_inc_min_tiles && (size_t)NS * (MS / 2) <= 255 && GPl <= 255 && MS / 2 <= 64 && GPl * NS <= nt &&
+                if (MS / 2 >= g_inc_min_tiles && (size_t)NS * (MS / 2) <= 255 && GPl <= 255 && MS / 2 <= 32 && GPl * NS <= nt &&
                     base + (size_t)g.qclass * 192 + need <= kLdsMax) {
                     g.inc = 1;
                     g.lcap = (int)lcap;

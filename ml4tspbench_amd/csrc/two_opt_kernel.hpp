@@ -151,6 +151,15 @@ __device__ __forceinline__ unsigned long long bit_range(int a, int b, int M)
     return (~0ull >> (63 - b)) & (~0ull << a);
 }
 
+// bits [a, b] of a 32-bit mask, clipped to [0, M-1] (M <= 32)
+__device__ __forceinline__ unsigned bit_range32(int a, int b, int M)
+{
+    a = a < 0 ? 0 : a;
+    b = b > M - 1 ? M - 1 : b;
+    if (a > b) return 0u;
+    return (~0u >> (31 - b)) & (~0u << a);
+}
+
 struct Unit {               // the lane's own unit, fixed for the whole kernel
     int gp;                 // lane group (of the whole tour), or -1 when the lane owns no unit
     int gpl;                // its index among this workgroup's lane groups
@@ -173,29 +182,27 @@ __device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, c
     if (!full) {
         const int MS2 = g.MS >> 1;
         const int i = (int)(last >> 16), j = (int)(last & 0xffffu);
-        unsigned long long mask = 0ull;
+        unsigned mask = 0u;                                 // touched tiles of the lane's unit (MS2 <= 32)
         if (un.gp >= 0) {
             for (int lo = i, hi = j; lo < g.W; lo += g.n, hi += g.n) {
-                mask |= bit_range((lo >> 3) - un.rq0, (hi >> 3) - un.rq0, MS2);                              // rows
-                mask |= bit_range(((lo - 9) >> 3) - un.gp - un.rq0, ((hi - 2) >> 3) - un.gp - un.rq0, MS2);  // columns
+                mask |= bit_range32((lo >> 3) - un.rq0, (hi >> 3) - un.rq0, MS2);                              // rows
+                mask |= bit_range32(((lo - 9) >> 3) - un.gp - un.rq0, ((hi - 2) >> 3) - un.gp - un.rq0, MS2);  // columns
             }
         }
-        // compaction: wave total -> one atomic -> per-lane positions by ballot rank
-        unsigned wtotal = 0;
-        for (int m2 = 0; m2 < MS2; ++m2) wtotal += (unsigned)__popcll(__ballot((mask >> m2) & 1ull));
-        unsigned base = 0;
+        // compaction: prefix sum of the lanes' counts -> one atomic per wave -> every lane writes its run
+        const unsigned cnt = (unsigned)__popc(mask);
+        const unsigned incl = wave_scan_add(cnt);
+        const unsigned wtotal = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
         if (wtotal) {
+            unsigned base = 0;
             if ((tid & 63) == 0) base = atomicAdd(&ctl->nlist, wtotal);
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            for (int m2 = 0; m2 < MS2; ++m2) {
-                const unsigned long long b = __ballot((mask >> m2) & 1ull);
-                if ((mask >> m2) & 1ull) {
-                    const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32),
-                                                    __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
-                    if (pos < (unsigned)g.lcap)
-                        v.list[pos] = (uint16_t)(((unsigned)(un.rq0 + m2) << 8) | (unsigned)un.gpl);
-                }
-                base += (unsigned)__popcll(b);
+            unsigned pos = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + incl - cnt;
+            const unsigned id0 = ((unsigned)un.rq0 << 8) | (unsigned)un.gpl;
+            while (mask) {
+                const unsigned b = (unsigned)__builtin_ctz(mask);
+                mask &= mask - 1u;
+                if (pos < (unsigned)g.lcap) v.list[pos] = (uint16_t)(id0 + (b << 8));
+                ++pos;
             }
         }
         FINE(pf, 0);                                        // marking + compaction

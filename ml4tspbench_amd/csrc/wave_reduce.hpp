@@ -59,4 +59,23 @@ __device__ __forceinline__ float wave_min(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// inclusive prefix sum over the wave (Hillis-Steele inside the rows of 16 lanes on row_shr, then the
+// row totals on row_bcast15 / row_bcast31); lanes without a source add 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned scan_step(unsigned x)
+{
+    return x + (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+
+__device__ __forceinline__ unsigned wave_scan_add(unsigned x)
+{
+    x = scan_step<0x111, 0xf>(x);       // row_shr:1
+    x = scan_step<0x112, 0xf>(x);       // row_shr:2
+    x = scan_step<0x114, 0xf>(x);       // row_shr:4
+    x = scan_step<0x118, 0xf>(x);       // row_shr:8
+    x = scan_step<0x142, 0xa>(x);       // row_bcast15 into rows 1 and 3
+    x = scan_step<0x143, 0xc>(x);       // row_bcast31 into rows 2 and 3
+    return x;
+}
+
 }  // namespace t2o
