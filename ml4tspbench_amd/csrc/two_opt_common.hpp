@@ -87,7 +87,7 @@ struct Ctl {                          // LDS control block (first bytes of dynam
     int flags;
     double bestE;
     unsigned bestIdx;
-    unsigned pad;
+    float spd;                        // cached filter value of the pair (0, n-1) (thread 0; find_best)
     double cx, cy, sc;
 };
 

@@ -166,6 +166,21 @@ struct Unit {               // the lane's own unit, fixed for the whole kernel
     int rq0;                // first 8-row block of its row segment
 };
 
+// Recomputed where it is needed rather than carried through the iteration loop: the kernel sits at
+// the VGPR limit and loop-carried registers are the ones that get spilled.
+template <bool CL>
+__device__ __forceinline__ Unit lane_unit(const Geo& g, int tid)
+{
+    Unit un{-1, 0, 0};
+    if (tid < g.GPl * g.NS) {
+        un.gpl = tid % g.GPl;
+        un.rq0 = (tid / g.GPl) * (g.MS >> 1);
+        const int gp = CL ? g.wc + g.CS * un.gpl : un.gpl;
+        if (!CL || gp < g.GP) un.gp = gp;
+    }
+    return un;
+}
+
 // Filter sweep of one iteration.  `last` = the reversal applied since the previous sweep (packed
 // (i, j)) or kFullSweep.  With the tile cache, only tiles that read a changed window position
 // (coordinates i+1..j, edges i..j, any cyclic copy) are recomputed: every lane marks its own
@@ -173,10 +188,11 @@ struct Unit {               // the lane's own unit, fixed for the whole kernel
 // atomic per wave), the list is processed evenly by all lanes, then every lane reduces its own
 // cached tile minima exactly as the full sweep would.
 template <int Q, bool CL, typename T>
-__device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid, const Unit& un,
+__device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid,
                                       unsigned last, float& a1, float& a2, unsigned& chunk, Prof& pf)
 {
     Ctl* ctl = v.ctl;
+    const Unit un = lane_unit<CL>(g, tid);
     bool full = !g.inc || last == kFullSweep;
     FINE_START(pf);
     if (!full) {
@@ -296,11 +312,12 @@ __device__ __forceinline__ void filter_chunk_pair(const View<T>& v, const Geo& g
 // continuation); otherwise a minimum proven >= -1e-6 by the filter alone ends the search.
 // CL (several workgroups per tour): this workgroup's tiles only, always exact (the result is compared
 // with the other workgroups' results), no fp32-only shortcut.
-// `spd` (thread 0 only): cached filter value of the pair (0, n-1); its operands P[1], P[n-1], e[0],
-// e[n-1] change only when the last reversal started at position 1 or ended at position n-1.
+// ctl->spd (thread 0 only): cached filter value of the pair (0, n-1); its operands P[1], P[n-1], e[0],
+// e[n-1] change only when the last reversal started at position 1 or ended at position n-1.  (In
+// LDS, not in a register: the kernel sits at the VGPR limit and loop-carried registers get spilled.)
 template <typename T, int Q, bool CL>
-__device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& un, bool need_exact_sign,
-                          unsigned last, float& spd, double& e, unsigned& idx, Prof& pf)
+__device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exact_sign,
+                          unsigned last, double& e, unsigned& idx, Prof& pf)
 {
     Ctl* ctl = v.ctl;
     unsigned long long t0 = 0;
@@ -315,7 +332,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& u
         // everything outside the sweep arithmetic is a latency chain that idles most of the
         // workgroup: it runs at high issue priority (set inside sweep()) so that the other
         // workgroups' sweeps on this SIMD do not stretch it
-        sweep<Q, CL>(v, g, tid, un, last, a1, a2, chunk, pf);
+        sweep<Q, CL>(v, g, tid, last, a1, a2, chunk, pf);
         if (pf.on) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
         const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
         const float wm = wave_min(a1);
@@ -376,9 +393,9 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, const Unit& u
                         const int s0 = slot<Q>(0), s1 = slot<Q>(1), sn1 = slot<Q>(n - 1), sn = slot<Q>(n);
                         const float d0 = dist32(v.Xq[s0].x, v.Yq[s0].x, v.Xq[sn1].x, v.Yq[sn1].x);
                         const float d1 = dist32(v.Xq[s1].x, v.Yq[s1].x, v.Xq[sn].x, v.Yq[sn].x);
-                        spd = ((d0 + d1) - v.Eq[sn1].x) - v.Eq[s0].x;
+                        ctl->spd = ((d0 + d1) - v.Eq[sn1].x) - v.Eq[s0].x;
                     }
-                    const float d = spd;
+                    const float d = ctl->spd;
                     const unsigned di = (unsigned)(n - 1);
                     if (d <= thr) {
                         multi = multi || (fidx != 0xffffffffu && fidx != di);
@@ -736,15 +753,6 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
     }
     T* xl = reinterpret_cast<T*>(smem + off);
     Ctl* ctl = v.ctl;
-    Unit un{-1, 0, 0};
-    if constexpr (Q != 0) {
-        if (tid < g.GPl * g.NS) {
-            un.gpl = tid % g.GPl;
-            un.rq0 = (tid / g.GPl) * (g.MS >> 1);
-            const int gp = CL ? g.wc + g.CS * un.gpl : un.gpl;
-            if (!CL || gp < g.GP) un.gp = gp;
-        }
-    }
     for (;;) {
         __syncthreads();
         int64_t tk;
@@ -882,11 +890,10 @@ __global__ void __launch_bounds__(1024) k_two_opt(Params p)
         bool have_prev = false, prev_active = false, active_at_target = false;
         unsigned prev_idx = kNoMove;
         unsigned last = kFullSweep;             // reversal applied since the previous sweep
-        float spd = 0.f;                        // thread 0: cached filter value of the pair (0, n-1)
         for (;;) {
             const bool check_only = forced && it >= target;
             if (check_only && target >= p.max_iter) break;
-            find_best<T, Q, CL>(v, g, tid, un, forced, last, spd, e, idx, pf);
+            find_best<T, Q, CL>(v, g, tid, forced, last, e, idx, pf);
             ++sweeps;
             unsigned xfl = 0;
             if constexpr (CL) {
