@@ -250,3 +250,31 @@ def test_gpu_tie_heavy_grids_all_kernels(amd, oracle, side, dtype):
         assert (status & (15 | 64)).max(initial=0) == 0, (mode, variant)
         assert np.array_equal(out, ref_out), (mode, variant)
         assert np.array_equal(iters, ref_it) and np.array_equal(sweeps, ref_sw), (mode, variant)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gpu_cluster_invalid_inputs_reported(amd, oracle, variant):
+    """Several workgroups per tour: every workgroup of a cluster must reach the same verdict on a bad
+    tour (index out of range, not closed, NaN coordinate), leave it untouched, and go on to the next."""
+    from ml4tspbench_amd import _lib
+    L = _lib.lib()
+    n = 800
+    rng = np.random.default_rng(321)
+    pts, tours = _random_batch(rng, 5, 1, n, np.float64)
+    bad = tours.copy()
+    bad[0, 17] = n + 3
+    bad[1, -1] = 9
+    p2 = pts.copy()
+    p2[2, 5, 1] = np.nan
+    L.tsp2opt_debug_cluster_mode(4)
+    L.tsp2opt_debug_tune(3, variant)
+    try:
+        out, iters, sweeps, _, status = _run(amd, p2, bad, 1, 1, 400)
+    finally:
+        L.tsp2opt_debug_cluster_mode(-1)
+        L.tsp2opt_debug_tune(3, 0)
+    assert status[0] & _lib.ST_BAD_INDEX and status[1] & _lib.ST_NOT_CLOSED and status[2] & _lib.ST_NONFINITE
+    assert np.array_equal(out[:3], bad[:3]) and (iters[:3] == 0).all() and (sweeps[:3] == 0).all()
+    ref_out, ref_it, _ = oracle.solve(pts[3:], tours[3:], max_iterations=400, threads=2)
+    assert (status[3:] & (15 | 64)).max() == 0
+    assert np.array_equal(out[3:], ref_out) and np.array_equal(iters[3:], ref_it)
