@@ -89,6 +89,50 @@ def cpu_baseline(name: str, pts: np.ndarray, tours: np.ndarray, tpi: int, group:
     }, out, iters, cpu_cap
 
 
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def dense_torch_baseline(pts: np.ndarray, tours: np.ndarray, tpi: int, budget_s: float = 4.0):
+    """The reference's COST STRUCTURE on the host (reported baseline only): a dense
+    torch formulation of the same best-improvement step -- all N x N deltas of a (P, N+1) batch as
+    tensors, argmin, host read-back, reversal -- written from the algorithm's definition,
+    fp64, torch CPU threads.  Timed per iteration on the first instance's tours for a bounded time."""
+    n = pts.shape[1]
+    P = torch.from_numpy(pts[0])
+    t = torch.from_numpy(tours[:tpi].copy())
+    torch_threads = torch.get_num_threads()
+    it, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and it < 200:
+        a, b = P[t[:, :-1]], P[t[:, 1:]]                            # (B, N, 2) edge tails and heads
+        d_aa = torch.cdist(a, a)                                    # D(t_i, t_j)
+        d_bb = torch.cdist(b, b)                                    # D(t_i+1, t_j+1)
+        e = (a - b).norm(dim=-1)                                    # D(t_i, t_i+1)
+        delta = torch.triu(d_aa + d_bb - e[:, :, None] - e[:, None, :], diagonal=2)
+        flat = delta.reshape(len(t), -1)
+        best, arg = flat.min(dim=1)
+        if float(best.min()) >= -1e-6:
+            break
+        for k in range(len(t)):
+            i, j = divmod(int(arg[k]), n)
+            if j > i:
+                t[k, i + 1:j + 1] = t[k, i + 1:j + 1].flip(0)
+        it += 1
+    dt = time.perf_counter() - t0
+    pairs = (n - 1) * (n - 2) // 2
+    return {"value": it * len(t) * pairs / dt if it else None, "unit": "pair-deltas/s",
+            "kind": "dense-torch formulation (cost structure of the reference, not its code)",
+            "torch_threads": torch_threads,
+            "sample": f"{len(t)} tours of one instance, {it} iterations, {dt:.1f} s"}
+
+
 def main():
     # stdout carries exactly ONE line, the JSON: everything else that libraries print there (RCCL's
     # version banner at communicator creation, for one) is sent to stderr until the line is due
@@ -265,7 +309,10 @@ def main():
             same = bool(np.array_equal(chk.tours[:k].cpu().numpy(), ref_out)
                         and np.array_equal(chk.iterations[:k].cpu().numpy(), ref_it))
             cb["gpu_matches_oracle_on_sample"] = same
+            cb["cpu_model"] = cpu_model()
             out["cpu_baseline"] = cb
+            if n <= 1000:
+                out["cpu_dense_torch"] = dense_torch_baseline(pts.astype(np.float64), tours, tpi)
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
         sys.stdout.flush()
         os.dup2(json_fd, 1)
