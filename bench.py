@@ -298,7 +298,7 @@ def main():
         }
         if gap is not None:
             out["fp32_vs_fp64"] = gap
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:       # the host baseline is timed at N = 1 only
             cb, ref_out, ref_it, cpu_cap = cpu_baseline(args.config, pts, tours, tpi, group,
                                                         args.max_iterations)
             k = len(ref_out)
