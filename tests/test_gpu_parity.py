@@ -168,7 +168,8 @@ def test_gpu_cluster_kernel_matches_oracle(amd, oracle, n, tours_n, dtype, cap, 
     L.tsp2opt_debug_cluster_mode(force if force else -1)
     L.tsp2opt_debug_tune(3, variant)
     try:
-        plan = _lib.cluster_plan(n, _lib.DTYPE_F64 if dtype == np.float64 else _lib.DTYPE_F32, tours_n, 256)
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        plan = _lib.cluster_plan(n, _lib.DTYPE_F64 if dtype == np.float64 else _lib.DTYPE_F32, tours_n, cus)
         assert plan["workgroups_per_tour"] >= 2, plan          # the case really runs a cluster kernel
         if variant:
             assert (plan["row_bands"] == 0) == (variant == 2), plan
