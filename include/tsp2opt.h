@@ -166,6 +166,9 @@ int tsp2opt_debug_greedy_cycles(int32_t enable, int32_t device, uint64_t* out8);
  */
 int tsp2opt_profile_enable(int32_t on);
 int tsp2opt_profile_last_ms(int32_t device, double* main_ms, double* forced_ms);
+/* The same for the call `calls_back` calls before the latest one on `device` (0 = latest, up to 63):
+ * lets a timed loop run without synchronising between its steps and read all durations afterwards. */
+int tsp2opt_profile_history_ms(int32_t device, int32_t calls_back, double* main_ms, double* forced_ms);
 
 /*
  * Diagnostic build aid (no counterpart in the reference): with on != 0 the persistent kernel also

@@ -41,6 +41,7 @@ SYMBOLS = (
     "tsp2opt_debug_greedy_cycles",
     "tsp2opt_profile_enable",
     "tsp2opt_profile_last_ms",
+    "tsp2opt_profile_history_ms",
     "tsp2opt_debug_phase_cycles",
     "tsp2opt_debug_sweep_only",
     "tsp2opt_debug_cluster_mode",
@@ -88,6 +89,8 @@ def lib() -> ctypes.CDLL:
     L.tsp2opt_profile_enable.restype = ctypes.c_int
     L.tsp2opt_profile_last_ms.argtypes = [i32, ctypes.POINTER(f64), ctypes.POINTER(f64)]
     L.tsp2opt_profile_last_ms.restype = ctypes.c_int
+    L.tsp2opt_profile_history_ms.argtypes = [i32, i32, ctypes.POINTER(f64), ctypes.POINTER(f64)]
+    L.tsp2opt_profile_history_ms.restype = ctypes.c_int
     L.tsp2opt_debug_phase_cycles.argtypes = [i32]
     L.tsp2opt_debug_phase_cycles.restype = ctypes.c_int
     L.tsp2opt_debug_sweep_only.argtypes = [i32]

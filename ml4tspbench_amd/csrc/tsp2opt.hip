@@ -69,11 +69,19 @@ namespace t2o {
 // host side
 // ------------------------------------------------------------------------------------------
 // optional timing of the persistent kernel with HIP events on the caller's stream
-// (tsp2opt_profile_enable / tsp2opt_profile_last_ms; used by bench.py for the roofline figure)
+// (tsp2opt_profile_enable / tsp2opt_profile_last_ms / tsp2opt_profile_history_ms; used by bench.py
+// for the roofline figure).  A ring of event sets per device: the last kProfRing calls stay readable,
+// so a timed loop needs no synchronisation between its steps.
 constexpr int kMaxDev = 16;
-struct ProfSlot {
+constexpr int kProfRing = 64;
+struct ProfEntry {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // main begin/end, forced begin/end
     bool have_main = false, have_forced = false;
+};
+struct ProfSlot {
+    ProfEntry ring[kProfRing];
+    long long calls = 0;                                        // profiled calls so far; current = (calls - 1) % ring
+    ProfEntry& cur() { return ring[(calls > 0 ? calls - 1 : 0) % kProfRing]; }
 };
 int g_profile = 0;
 int g_dbg_sweeps = 0;                // diagnostic: filter sweeps only (tsp2opt_debug_sweep_only)
@@ -83,7 +91,11 @@ ProfSlot g_prof[kMaxDev];
 int prof_record(int device, int which, hipStream_t stream)
 {
     if (!g_profile || device < 0 || device >= kMaxDev) return 0;
-    ProfSlot& s = g_prof[device];
+    if (which == 0) {                                           // a new call: next ring entry
+        ++g_prof[device].calls;
+        g_prof[device].cur().have_main = g_prof[device].cur().have_forced = false;
+    }
+    ProfEntry& s = g_prof[device].cur();
     if (!s.ev[which]) HIP_TRY(hipEventCreate(&s.ev[which]));
     HIP_TRY(hipEventRecord(s.ev[which], stream));
     return 0;
@@ -478,7 +490,7 @@ int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* swe
     }
     rc = prof_record(device, 1, stream);
     if (rc) return rc;
-    if (g_profile && device < kMaxDev) { g_prof[device].have_main = true; g_prof[device].have_forced = false; }
+    if (g_profile && device < kMaxDev) g_prof[device].cur().have_main = true;
     const unsigned tb = 256;
     const unsigned tgrid = (unsigned)((num_tours + tb - 1) / tb);
     if (group_size > 1) {
@@ -495,7 +507,7 @@ int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* swe
         if (rc) return rc;
         rc = prof_record(device, 3, stream);
         if (rc) return rc;
-        if (g_profile && device < kMaxDev) g_prof[device].have_forced = true;
+        if (g_profile && device < kMaxDev) g_prof[device].cur().have_forced = true;
         const int lnt = n <= 256 ? 256 : 1024;
         const size_t llds = align16(sizeof(Ctl)) + align16(sizeof(uint16_t) * (size_t)(n + 1)) +
                             align16(sizeof(unsigned) * (size_t)group_size);
@@ -675,10 +687,13 @@ extern "C" int tsp2opt_profile_enable(int32_t on)
     return 0;
 }
 
-extern "C" int tsp2opt_profile_last_ms(int32_t device, double* main_ms, double* forced_ms)
+extern "C" int tsp2opt_profile_history_ms(int32_t device, int32_t calls_back, double* main_ms, double* forced_ms)
 {
-    if (device < 0 || device >= kMaxDev || !main_ms) return fail(TSP2OPT_E_ARG, "bad argument");
-    ProfSlot& s = g_prof[device];
+    if (device < 0 || device >= kMaxDev || !main_ms || calls_back < 0 || calls_back >= kProfRing)
+        return fail(TSP2OPT_E_ARG, "bad argument");
+    ProfSlot& slot = g_prof[device];
+    if (slot.calls - calls_back < 1) return fail(TSP2OPT_E_ARG, "no such profiled call on this device");
+    ProfEntry& s = slot.ring[(slot.calls - 1 - calls_back) % kProfRing];
     if (!s.have_main) return fail(TSP2OPT_E_ARG, "no profiled call on this device");
     DeviceGuard guard(device);
     if (!guard.ok) return fail(TSP2OPT_E_HIP, "hipSetDevice failed");
@@ -695,6 +710,11 @@ extern "C" int tsp2opt_profile_last_ms(int32_t device, double* main_ms, double* 
         }
     }
     return 0;
+}
+
+extern "C" int tsp2opt_profile_last_ms(int32_t device, double* main_ms, double* forced_ms)
+{
+    return tsp2opt_profile_history_ms(device, 0, main_ms, forced_ms);
 }
 
 // Diagnostic: with on != 0, wave 0 lane 0 of every workgroup accumulates shader-clock cycles per

@@ -279,3 +279,27 @@ def test_gpu_cluster_invalid_inputs_reported(amd, oracle, variant):
     ref_out, ref_it, _ = oracle.solve(pts[3:], tours[3:], max_iterations=400, threads=2)
     assert (status[3:] & (15 | 64)).max() == 0
     assert np.array_equal(out[3:], ref_out) and np.array_equal(iters[3:], ref_it)
+
+
+def test_gpu_profile_history(amd):
+    """tsp2opt_profile_history_ms: the HIP-event durations of the last calls stay readable afterwards."""
+    import ctypes
+    from ml4tspbench_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    pts = torch.from_numpy(rng.random((4, 60, 2))).cuda()
+    tours = torch.from_numpy(np.stack([np.append(rng.permutation(60), 0) for _ in range(4)]).astype(np.int64))
+    tours = torch.where(tours == 0, tours[:, :1], torch.where(tours == tours[:, :1], 0, tours)).cuda()
+    L.tsp2opt_profile_enable(1)
+    try:
+        for _ in range(3):
+            amd.two_opt_device(pts, tours)
+        torch.cuda.synchronize()
+        m, f = ctypes.c_double(), ctypes.c_double()
+        for back in range(3):
+            assert L.tsp2opt_profile_history_ms(0, back, ctypes.byref(m), ctypes.byref(f)) == 0
+            assert 0.0 < m.value < 1000.0
+        assert L.tsp2opt_profile_history_ms(0, 64, ctypes.byref(m), ctypes.byref(f)) != 0
+        assert L.tsp2opt_profile_last_ms(0, ctypes.byref(m), ctypes.byref(f)) == 0
+    finally:
+        L.tsp2opt_profile_enable(0)
