@@ -303,3 +303,26 @@ def test_gpu_profile_history(amd):
         assert L.tsp2opt_profile_last_ms(0, ctypes.byref(m), ctypes.byref(f)) == 0
     finally:
         L.tsp2opt_profile_enable(0)
+
+
+@pytest.mark.parametrize("lo,hi,step,force", [(4, 200, 1, 0), (201, 700, 13, 0), (18, 330, 8, 3)])
+def test_gpu_every_n_matches_oracle(amd, oracle, lo, hi, step, force):
+    """Geometry boundaries (threads per workgroup, filter class, tile cache on/off, cluster split):
+    a grid of N through the automatic kernel choice and through forced clusters, both dtypes."""
+    from ml4tspbench_amd import _lib
+    L = _lib.lib()
+    L.tsp2opt_debug_cluster_mode(force if force else -1)
+    bad = []
+    try:
+        for n in range(lo, hi + 1, step):
+            for dtype in (np.float64, np.float32):
+                rng = np.random.default_rng(n * 3 + (dtype == np.float32))
+                pts, tours = _random_batch(rng, 3, 1, n, dtype)
+                ref_out, ref_it, ref_sw = oracle.solve(pts, tours, max_iterations=5000, threads=8)
+                out, iters, sweeps, _, status = _run(amd, pts, tours, 1, 1, 5000)
+                if not (np.array_equal(out, ref_out) and np.array_equal(iters, ref_it)
+                        and np.array_equal(sweeps, ref_sw) and (status & (15 | 64)).max(initial=0) == 0):
+                    bad.append((n, dtype.__name__))
+    finally:
+        L.tsp2opt_debug_cluster_mode(-1)
+    assert not bad, bad
