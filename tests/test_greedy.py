@@ -87,3 +87,41 @@ def test_gpu_greedy_matches_oracle_random(n, inst, mpi, dtype):
     assert ((ev.valid.cpu().numpy() & 7) == 7).all()
     l0 = evaluate_tours(d_pts, tours, tours_per_instance=mpi).lengths
     assert (ev.lengths <= l0 + 1e-9).all()
+
+
+def _fuzz_maps(rng, n, kind, dtype, inst=2, mpi=2):
+    pts = rng.random((inst, n, 2))
+    heat = rng.random((inst * mpi, n, n))
+    if kind == "sparse":                               # a few nonzero entries per row, the rest exactly 0
+        k = min(n - 1, 5)
+        heat = np.where(heat >= np.sort(heat, axis=2)[:, :, n - k][:, :, None], heat, 0.0)
+    elif kind == "ties":                               # quantised heat: equal values stress the list refills
+        heat = np.round(heat * 4) / 4
+    elif kind == "grid":                               # lattice points + quantised heat: exactly equal keys
+        side = int(np.ceil(np.sqrt(n)))
+        g = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2)[:n] / side
+        pts = np.stack([g, g[::-1]]).astype(np.float64)
+        heat = np.round(heat * 2) / 2
+    return pts, heat.astype(dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dense", "sparse", "ties", "grid"])
+def test_gpu_greedy_grid_of_n(kind):
+    """A grid of N (list lengths, scan widths, row tails) x map kinds, both dtypes, against the oracle."""
+    from ml4tspbench_amd import greedy_decode_device
+    from oracle import greedy_oracle
+    dev = torch.device("cuda", 0)
+    bad = []
+    for n in list(range(3, 70)) + list(range(70, 270, 11)) + [511, 777]:
+        rng = np.random.default_rng(n)
+        for dtype in (np.float32, np.float64):
+            pts, heat = _fuzz_maps(rng, n, kind, dtype)
+            got = greedy_decode_device(torch.from_numpy(heat).to(dev), torch.from_numpy(pts).to(dev),
+                                       maps_per_instance=2)
+            torch.cuda.synchronize()
+            got = got.cpu().numpy()
+            for m in range(heat.shape[0]):
+                if not np.array_equal(got[m], greedy_oracle.greedy(pts[m // 2], heat[m])[0]):
+                    bad.append((n, dtype.__name__, m))
+    assert not bad, bad
