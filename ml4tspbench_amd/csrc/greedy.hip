@@ -209,15 +209,21 @@ struct GreedyLds {          // carve of the dynamic LDS for one heat map (one wa
 };
 
 // The minimum candidate key of every group of 64 nodes lives in registers: lane l holds groups l
-// (gm0) and l + 64 (gm1); +inf = no candidate in the group.  Refresh the minimum of node x's group
-// after its candidate changed (all 64 lanes).
-__device__ __forceinline__ void refresh_group(const GreedyLds& L, int n, int x, int lane, float& gm0, float& gm1)
+// (gm0), l + 64 (gm1) and, for n > 8192 (BIG kernels only), l + 128 (gm2); +inf = no candidate in the
+// group.  Refresh the minimum of node x's group after its candidate changed (all 64 lanes).
+template <bool BIG>
+__device__ __forceinline__ void refresh_group(const GreedyLds& L, int n, int x, int lane, float& gm0, float& gm1,
+                                              float& gm2)
 {
     if (n <= 128) return;                               // two groups at most: scanned directly
     const int g = x >> 6, k = (g << 6) + lane;
     const float v = k < n ? L.cand[k].key : __builtin_nanf("");
     const float m = wave_min(v != v ? INFINITY : v);
-    if (lane == (g & 63)) { if (g < 64) gm0 = m; else gm1 = m; }
+    if (lane == (g & 63)) {
+        if (g < 64) gm0 = m;
+        else if (!BIG || g < 128) gm1 = m;
+        else gm2 = m;
+    }
 }
 
 // can node i still take partner j?  (j is a fragment endpoint of another fragment)
@@ -255,6 +261,7 @@ __device__ __forceinline__ void rescan(const GreedyLds& L, const double* __restr
 // node i's candidate is no longer valid: the next valid entry of its list, else a rescan
 __device__ __forceinline__ bool advance(const GreedyLds& L, int K, int i, int lane)
 {
+    if (K == 0) return false;                           // large n: no lists in LDS, every replacement is a rescan
     const int p0 = L.lp[i], oe = L.oend[i];
     bool ok = false;
     if (lane > p0 && lane < K) ok = partner_ok(L, i, oe, L.lj[i * K + lane]);
@@ -271,7 +278,8 @@ __device__ __forceinline__ bool advance(const GreedyLds& L, int K, int i, int la
     return true;
 }
 
-// K = list entries kept per node in LDS (kTopK, or fewer when n is large); W: see rescan
+// K = list entries kept per node in LDS (kTopK, or fewer when n is large, none above kGreedyListMaxN);
+// W: see rescan (the W = 16 kernel is also the one that carries the third group-minimum register)
 template <int W>
 __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, const float* __restrict__ lkey,
                                               const uint16_t* __restrict__ lj0, int64_t* __restrict__ tours,
@@ -290,13 +298,14 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
     L.oend = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n;
     L.nb = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * 2 * (size_t)n;
     L.deg = reinterpret_cast<uint8_t*>(smem + off); off += (size_t)n;
-    L.lp = reinterpret_cast<uint8_t*>(smem + off);
+    L.lp = reinterpret_cast<uint8_t*>(smem + off);      // unused (and outside the allocation) when K == 0
+    constexpr bool BIG = W == 16;
     const double* Kb = Kd + (size_t)b * (size_t)n * (size_t)n;
     for (int i = lane; i < n; i += 64) {
         L.oend[i] = (uint16_t)i;
         L.nb[2 * i] = L.nb[2 * i + 1] = 0xffffu;
         L.deg[i] = 0;
-        L.lp[i] = 0;
+        if (K) L.lp[i] = 0;
         const size_t src = ((size_t)b * n + i) * kTopK;
         for (int p = 0; p < K; ++p) {
             L.lk[i * K + p] = lkey[src + p];
@@ -305,8 +314,8 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
         L.cand[i] = Cand{lkey[src], lj0[src]};          // first candidates: the heads of the lists
     }
     __builtin_amdgcn_wave_barrier();
-    float gm0 = INFINITY, gm1 = INFINITY;
-    for (int g = 0; g < G; ++g) refresh_group(L, n, g << 6, lane, gm0, gm1);
+    float gm0 = INFINITY, gm1 = INFINITY, gm2 = INFINITY;
+    for (int g = 0; g < G; ++g) refresh_group<BIG>(L, n, g << 6, lane, gm0, gm1, gm2);
     __builtin_amdgcn_wave_barrier();
 
     int merges = 0;
@@ -319,7 +328,7 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
         // only when more than one node does and they do not simply name each other
         const unsigned long long t0 = prof ? clock64() : 0;
         float m;
-        unsigned long long gb0 = 0ull, gb1 = 0ull;
+        unsigned long long gb0 = 0ull, gb1 = 0ull, gb2 = 0ull;
         int i = -1, second = -1, hits = 0;
         unsigned cji = 0, cjs = 0;                      // partners of i and second
         auto take = [&](unsigned long long bal, int base, unsigned cjl) {
@@ -339,14 +348,16 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
             take(bal, 0, c0.cj);
             take(bal1, 64, c1.cj);
         } else {
-            m = wave_min(fminf(gm0, gm1));
+            m = wave_min(BIG ? fminf(fminf(gm0, gm1), gm2) : fminf(gm0, gm1));
             gb0 = __ballot(gm0 == m);
             gb1 = __ballot(gm1 == m);
+            if (BIG) gb2 = __ballot(gm2 == m);
         }
-        while (gb0 | gb1) {                             // groups whose minimum is m (usually one)
+        while (gb0 | gb1 | gb2) {                       // groups whose minimum is m (usually one)
             int g;
             if (gb0) { g = __ffsll((long long)gb0) - 1; gb0 &= gb0 - 1; }
-            else { g = 64 + __ffsll((long long)gb1) - 1; gb1 &= gb1 - 1; }
+            else if (gb1) { g = 64 + __ffsll((long long)gb1) - 1; gb1 &= gb1 - 1; }
+            else { g = 128 + __ffsll((long long)gb2) - 1; gb2 &= gb2 - 1; }
             const int k = (g << 6) + lane;
             const Cand c = k < n ? L.cand[k] : Cand{__builtin_nanf(""), 0u};
             const unsigned long long bal = __ballot(c.key == m);
@@ -388,12 +399,12 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
             }
             ++merges;
             __builtin_amdgcn_wave_barrier();
-            refresh_group(L, n, i, lane, gm0, gm1);
-            if ((j >> 6) != (i >> 6)) refresh_group(L, n, j, lane, gm0, gm1);
+            refresh_group<BIG>(L, n, i, lane, gm0, gm1, gm2);
+            if ((j >> 6) != (i >> 6)) refresh_group<BIG>(L, n, j, lane, gm0, gm1, gm2);
         } else {
             if (!advance(L, K, i, lane)) rescan<W>(L, Kb, n, i, lane);
             __builtin_amdgcn_wave_barrier();
-            refresh_group(L, n, i, lane, gm0, gm1);
+            refresh_group<BIG>(L, n, i, lane, gm0, gm1, gm2);
         }
         __builtin_amdgcn_wave_barrier();
         if (prof) {
@@ -435,17 +446,19 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
     }
 }
 
-constexpr int kGreedyMaxN = 4500;
+constexpr int kGreedyListMaxN = 4500;   // lists of 2 fit the LDS of one wave's heat map up to here
+constexpr int kGreedyMaxN = 10900;      // 15 B of state per node in 160 KB; 171 groups of 64 nodes (<= 192)
 
 // list entries per node (extracted by the prepare kernel and kept in LDS by the merge loop): kTopK
-// while a heat map's state stays near 64 KB; 2 for larger n; 1 (the row's best only) for small n,
-// where tracking and extracting more costs the prepare kernel more than the merge loop gains
-inline int greedy_k(int n) { return n <= 128 ? 1 : n <= 1700 ? kTopK : 2; }
+// while a heat map's state stays near 64 KB; 2 for larger n; none above kGreedyListMaxN (the state of
+// a TSP-10000 map alone is 150 KB: every replacement is a row rescan); 1 (the row's best only) for small
+// n, where tracking and extracting more costs the prepare kernel more than the merge loop gains
+inline int greedy_k(int n) { return n <= 128 ? 1 : n <= 1700 ? kTopK : n <= kGreedyListMaxN ? 2 : 0; }
 
 inline size_t greedy_lds(int n)
 {
     const int K = greedy_k(n);
-    return (size_t)n * (8 + 6 * (size_t)K + 2 + 4 + 1 + 1) + 64;
+    return (size_t)n * (8 + 6 * (size_t)K + 2 + 4 + 1 + (K ? 1 : 0)) + 64;
 }
 
 struct GreedyWs {
@@ -478,7 +491,7 @@ int greedy_t(const void* heat, const double* points, int64_t* tours, int64_t num
     // grid.y is limited to 65535: prepare in slabs of heat maps
     for (int64_t b0 = 0; b0 < num_maps; b0 += 32768) {
         const dim3 grid((unsigned)((n + 31) / 32), (unsigned)std::min<int64_t>(32768, num_maps - b0), 1);
-        if (greedy_k(n) == 1)
+        if (greedy_k(n) <= 1)       // the row's best only (it is also every node's first candidate when K = 0)
             hipLaunchKernelGGL((k_greedy_prepare<H, 1>), grid, dim3(64, 8), 0, stream, A, points, Kd, lkey, lj, n, mpi, b0, 1);
         else
             hipLaunchKernelGGL((k_greedy_prepare<H, 2>), grid, dim3(64, 8), 0, stream, A, points, Kd, lkey, lj, n, mpi, b0, greedy_k(n));
@@ -511,7 +524,7 @@ extern "C" int tsp2opt_greedy_decode(const void* heat, const double* points, int
                                      int64_t workspace_bytes, void* hip_stream)
 {
     if (num_maps < 0 || n < 2 || maps_per_instance < 1) return fail(TSP2OPT_E_ARG, "bad size");
-    if (n > kGreedyMaxN) return fail(TSP2OPT_E_UNSUPPORTED, "greedy decode supports n <= 4500");
+    if (n > kGreedyMaxN) return fail(TSP2OPT_E_UNSUPPORTED, "greedy decode supports n <= 10900");
     if (heat_dtype != TSP2OPT_DTYPE_F32 && heat_dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
     if (num_maps == 0) return 0;
     if (!heat || !points || !tours_out || !workspace) return fail(TSP2OPT_E_ARG, "null pointer");

@@ -65,7 +65,9 @@ def test_gpu_greedy_matches_reference_golden(path):
                                              (1000, 2, 1, np.float32),
                                              # list lengths 1 / 4 / 2 and both rescan widths
                                              (128, 3, 2, np.float32), (130, 4, 2, np.float64),
-                                             (513, 2, 1, np.float32), (1800, 1, 1, np.float32)])
+                                             (513, 2, 1, np.float32), (1800, 1, 1, np.float32),
+                                             # no lists in LDS (n > 4500); third group-minimum register (n > 8192)
+                                             (4600, 1, 2, np.float32), (8300, 1, 1, np.float32)])
 def test_gpu_greedy_matches_oracle_random(n, inst, mpi, dtype):
     from ml4tspbench_amd import greedy_decode_device, two_opt_device, evaluate_tours
     from oracle import greedy_oracle
