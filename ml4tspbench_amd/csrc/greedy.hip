@@ -206,6 +206,13 @@ struct GreedyLds {          // carve of the dynamic LDS for one heat map (one wa
     uint16_t* nb;           // 2 neighbour slots per node, 0xffff = empty
     uint8_t* deg;
     uint8_t* lp;            // cursor into the node's list (K: list used up, candidates come from rescans)
+    int* cmd;               // NW > 1: row to rescan (or -1: done), published by wave 0 to the helper waves
+    struct Part* part;      // NW > 1: every wave's best valid partner of that row
+};
+
+struct Part {
+    double k;
+    unsigned j, pad;
 };
 
 // The minimum candidate key of every group of 64 nodes lives in registers: lane l holds groups l
@@ -236,14 +243,16 @@ __device__ __forceinline__ bool partner_ok(const GreedyLds& L, int i, int oe, in
 // row's keys are loaded unconditionally, W per lane in flight (8: n <= 512 in one global round trip
 // within 64 VGPRs, i.e. 8 heat maps per SIMD; 16 for larger n, where there are fewer maps than
 // SIMDs anyway).  Result stored by lane 0.
-template <int W>
-__device__ __forceinline__ void rescan(const GreedyLds& L, const double* __restrict__ Kb, int n, int i, int lane)
+// NW waves share a row: wave w takes the columns [64 W (w + NW t), 64 W (w + NW t + 1)), t = 0, 1, ...
+template <int W, int NW>
+__device__ __forceinline__ void rescan_part(const GreedyLds& L, const double* __restrict__ Kb, int n, int i, int lane,
+                                            int wave, double& bk, unsigned& bj)
 {
     const double* Krow = Kb + (size_t)i * n;
     const int oe = L.oend[i];
-    double bk = INFINITY;
-    unsigned bj = 0xffffu;
-    for (int j0 = lane; j0 < n; j0 += 64 * W) {
+    bk = INFINITY;
+    bj = 0xffffu;
+    for (int j0 = wave * 64 * W + lane; j0 < n; j0 += 64 * W * NW) {
         double k[W];
 #pragma unroll
         for (int u = 0; u < W; ++u) k[u] = j0 + 64 * u < n ? Krow[j0 + 64 * u] : INFINITY;
@@ -255,7 +264,43 @@ __device__ __forceinline__ void rescan(const GreedyLds& L, const double* __restr
         }
     }
     wave_best(bk, bj);
+}
+
+// wave 0's side of a rescan.  NW > 1 (large maps, one workgroup per heat map): the helper waves sleep
+// at a barrier between rescans (helper_loop); wave 0 publishes the row, everybody scans a share of it,
+// wave 0 reduces the NW partial results.
+template <int W, int NW>
+__device__ __forceinline__ void rescan(const GreedyLds& L, const double* __restrict__ Kb, int n, int i, int lane)
+{
+    double bk;
+    unsigned bj;
+    if constexpr (NW > 1) {
+        if (lane == 0) L.cmd[0] = i;
+        __syncthreads();
+        rescan_part<W, NW>(L, Kb, n, i, lane, 0, bk, bj);
+        __syncthreads();
+        if (lane >= 1 && lane < NW) { bk = L.part[lane].k; bj = L.part[lane].j; }
+        else if (lane != 0) { bk = INFINITY; bj = 0xffffu; }
+        wave_best(bk, bj);
+    } else {
+        rescan_part<W, 1>(L, Kb, n, i, lane, 0, bk, bj);
+    }
     if (lane == 0) L.cand[i] = Cand{bj == 0xffffu ? __builtin_nanf("") : (float)bk, bj};
+}
+
+template <int W, int NW>
+__device__ __forceinline__ void helper_loop(const GreedyLds& L, const double* __restrict__ Kb, int n, int lane, int wave)
+{
+    for (;;) {
+        __syncthreads();                                // wave 0 has published a row, or the end
+        const int i = L.cmd[0];
+        if (i < 0) return;
+        double bk;
+        unsigned bj;
+        rescan_part<W, NW>(L, Kb, n, i, lane, wave, bk, bj);
+        if (lane == 0) L.part[wave] = Part{bk, bj, 0u};
+        __syncthreads();                                // partial results are in LDS
+    }
 }
 
 // node i's candidate is no longer valid: the next valid entry of its list, else a rescan
@@ -280,16 +325,18 @@ __device__ __forceinline__ bool advance(const GreedyLds& L, int K, int i, int la
 
 // K = list entries kept per node in LDS (kTopK, or fewer when n is large, none above kGreedyListMaxN);
 // W: see rescan (the W = 16 kernel is also the one that carries the third group-minimum register)
-template <int W>
-__global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, const float* __restrict__ lkey,
+// NW = waves per heat map: 1 (many maps side by side on a CU) or 16 for maps above kGreedyListMaxN
+// nodes, whose state fills a CU's LDS anyway and whose every replacement is a rescan of a long row
+template <int W, int NW>
+__global__ void __launch_bounds__(64 * NW) k_greedy(const double* __restrict__ Kd, const float* __restrict__ lkey,
                                               const uint16_t* __restrict__ lj0, int64_t* __restrict__ tours,
                                               int64_t num_maps, int n, int K, int prof)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int64_t b = blockIdx.x;
     if (b >= num_maps) return;
-    const int lane = threadIdx.x;
-    const int G = (n + 63) >> 6;                        // groups of 64 nodes, <= 128
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int G = (n + 63) >> 6;                        // groups of 64 nodes, <= 192
     GreedyLds L;
     size_t off = 0;
     L.cand = reinterpret_cast<Cand*>(smem + off); off += sizeof(Cand) * (size_t)n;
@@ -298,10 +345,13 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
     L.oend = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n;
     L.nb = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * 2 * (size_t)n;
     L.deg = reinterpret_cast<uint8_t*>(smem + off); off += (size_t)n;
-    L.lp = reinterpret_cast<uint8_t*>(smem + off);      // unused (and outside the allocation) when K == 0
+    L.lp = reinterpret_cast<uint8_t*>(smem + off);      // unused (and empty) when K == 0
+    off = (off + (K ? (size_t)n : 0) + 15) & ~(size_t)15;
+    L.cmd = reinterpret_cast<int*>(smem + off);         // NW > 1 only (greedy_lds)
+    L.part = reinterpret_cast<Part*>(smem + off + 16);
     constexpr bool BIG = W == 16;
     const double* Kb = Kd + (size_t)b * (size_t)n * (size_t)n;
-    for (int i = lane; i < n; i += 64) {
+    for (int i = threadIdx.x; i < n; i += 64 * NW) {
         L.oend[i] = (uint16_t)i;
         L.nb[2 * i] = L.nb[2 * i + 1] = 0xffffu;
         L.deg[i] = 0;
@@ -312,6 +362,10 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
             L.lj[i * K + p] = lj0[src + p];
         }
         L.cand[i] = Cand{lkey[src], lj0[src]};          // first candidates: the heads of the lists
+    }
+    if constexpr (NW > 1) {
+        __syncthreads();
+        if (wave != 0) { helper_loop<W, NW>(L, Kb, n, lane, wave); return; }
     }
     __builtin_amdgcn_wave_barrier();
     float gm0 = INFINITY, gm1 = INFINITY, gm2 = INFINITY;
@@ -402,7 +456,7 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
             refresh_group<BIG>(L, n, i, lane, gm0, gm1, gm2);
             if ((j >> 6) != (i >> 6)) refresh_group<BIG>(L, n, j, lane, gm0, gm1, gm2);
         } else {
-            if (!advance(L, K, i, lane)) rescan<W>(L, Kb, n, i, lane);
+            if (!advance(L, K, i, lane)) rescan<W, NW>(L, Kb, n, i, lane);
             __builtin_amdgcn_wave_barrier();
             refresh_group<BIG>(L, n, i, lane, gm0, gm1, gm2);
         }
@@ -412,6 +466,10 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
             t_scan += t1 - t0;
             if (valid) t_merge += t2 - t1; else { t_rescan += t2 - t1; ++n_rescan; }
         }
+    }
+    if constexpr (NW > 1) {                             // release the helper waves
+        if (lane == 0) L.cmd[0] = -1;
+        __syncthreads();
     }
     if (prof && lane == 0) {
         atomicAdd(&g_greedy_prof[0], t_scan);
@@ -447,7 +505,8 @@ __global__ void __launch_bounds__(64) k_greedy(const double* __restrict__ Kd, co
 }
 
 constexpr int kGreedyListMaxN = 4500;   // lists of 2 fit the LDS of one wave's heat map up to here
-constexpr int kGreedyMaxN = 10900;      // 15 B of state per node in 160 KB; 171 groups of 64 nodes (<= 192)
+constexpr int kGreedyMaxN = 10800;      // 15 B of state per node in 160 KB; 169 groups of 64 nodes (<= 192)
+constexpr int kGreedyBigWaves = 16;     // waves per heat map above kGreedyListMaxN nodes
 
 // list entries per node (extracted by the prepare kernel and kept in LDS by the merge loop): kTopK
 // while a heat map's state stays near 64 KB; 2 for larger n; none above kGreedyListMaxN (the state of
@@ -458,7 +517,8 @@ inline int greedy_k(int n) { return n <= 128 ? 1 : n <= 1700 ? kTopK : n <= kGre
 inline size_t greedy_lds(int n)
 {
     const int K = greedy_k(n);
-    return (size_t)n * (8 + 6 * (size_t)K + 2 + 4 + 1 + (K ? 1 : 0)) + 64;
+    return (size_t)n * (8 + 6 * (size_t)K + 2 + 4 + 1 + (K ? 1 : 0)) + 64 +
+           (K ? 0 : 32 + sizeof(Part) * kGreedyBigWaves);
 }
 
 struct GreedyWs {
@@ -498,11 +558,12 @@ int greedy_t(const void* heat, const double* points, int64_t* tours, int64_t num
         HIP_TRY(hipGetLastError());
     }
     const size_t lds = greedy_lds(n);
-    auto kern = n <= 512 ? k_greedy<8> : k_greedy<16>;
+    const bool big = greedy_k(n) == 0;
+    auto kern = n <= 512 ? k_greedy<8, 1> : big ? k_greedy<16, kGreedyBigWaves> : k_greedy<16, 1>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)num_maps), dim3(64), lds, stream, Kd, lkey, lj, tours,
-                       num_maps, n, greedy_k(n), g_greedy_prof_on);
+    hipLaunchKernelGGL(kern, dim3((unsigned)num_maps), dim3(big ? 64 * kGreedyBigWaves : 64), lds, stream, Kd,
+                       lkey, lj, tours, num_maps, n, greedy_k(n), g_greedy_prof_on);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -524,7 +585,7 @@ extern "C" int tsp2opt_greedy_decode(const void* heat, const double* points, int
                                      int64_t workspace_bytes, void* hip_stream)
 {
     if (num_maps < 0 || n < 2 || maps_per_instance < 1) return fail(TSP2OPT_E_ARG, "bad size");
-    if (n > kGreedyMaxN) return fail(TSP2OPT_E_UNSUPPORTED, "greedy decode supports n <= 10900");
+    if (n > kGreedyMaxN) return fail(TSP2OPT_E_UNSUPPORTED, "greedy decode supports n <= 10800");
     if (heat_dtype != TSP2OPT_DTYPE_F32 && heat_dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
     if (num_maps == 0) return 0;
     if (!heat || !points || !tours_out || !workspace) return fail(TSP2OPT_E_ARG, "null pointer");
