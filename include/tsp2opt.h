@@ -131,7 +131,7 @@ int tsp2opt_evaluate(const void* points, const int64_t* tours, double* lengths_o
  *   workspace at least tsp2opt_greedy_workspace_bytes(...) bytes (holds A + A^T)
  * Edges are taken in increasing order of -A_ij/|v_i-v_j| (double); exactly equal keys of different
  * edges are ordered by flat index i*n+j (the reference's order for ties is numpy's unstable argsort:
- * undefined).  n <= 10800 (the state of one heat map, 15 B per node, lives in the LDS of one wave).
+ * undefined).  n <= 10200 (the state of one heat map, 16 B per node, lives in the LDS of one wave).
  */
 int tsp2opt_greedy_decode(const void* heat, const double* points, int64_t* tours_out,
                           int64_t num_maps, int32_t n, int32_t maps_per_instance, int32_t heat_dtype,

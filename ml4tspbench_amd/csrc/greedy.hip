@@ -304,9 +304,35 @@ __device__ __forceinline__ void helper_loop(const GreedyLds& L, const double* __
 }
 
 // node i's candidate is no longer valid: the next valid entry of its list, else a rescan
-__device__ __forceinline__ bool advance(const GreedyLds& L, int K, int i, int lane)
+__device__ __forceinline__ bool advance(const GreedyLds& L, int K, int i, int lane, const float* __restrict__ glk,
+                                        const uint16_t* __restrict__ glj)
 {
-    if (K == 0) return false;                           // large n: no lists in LDS, every replacement is a rescan
+    if (K == 0) {
+        // large n: no room for the lists in LDS, they are read where the prepare kernel left them (kTopK
+        // entries per node, one global round trip: still less than half of a row rescan)
+        const int p0 = L.lp[i], oe = L.oend[i];
+        if (p0 >= kTopK - 1) {
+            if (lane == 0) L.lp[i] = (uint8_t)kTopK;
+            return false;
+        }
+        float k = 0.f;
+        unsigned j = 0xffffu;
+        if (lane < kTopK) { k = glk[(size_t)i * kTopK + lane]; j = glj[(size_t)i * kTopK + lane]; }
+        const bool ok = lane > p0 && lane < kTopK && partner_ok(L, i, oe, (int)j);
+        const unsigned long long bal = __ballot(ok);
+        if (!bal) {
+            if (lane == 0) L.lp[i] = (uint8_t)kTopK;
+            return false;
+        }
+        const int p = __ffsll((long long)bal) - 1;
+        const float pk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, k), p));
+        const unsigned pj = (unsigned)__builtin_amdgcn_readlane((int)j, p);
+        if (lane == 0) {
+            L.lp[i] = (uint8_t)p;
+            L.cand[i] = Cand{pk, pj};
+        }
+        return true;
+    }
     const int p0 = L.lp[i], oe = L.oend[i];
     bool ok = false;
     if (lane > p0 && lane < K) ok = partner_ok(L, i, oe, L.lj[i * K + lane]);
@@ -345,8 +371,8 @@ __global__ void __launch_bounds__(64 * NW) k_greedy(const double* __restrict__ K
     L.oend = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n;
     L.nb = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * 2 * (size_t)n;
     L.deg = reinterpret_cast<uint8_t*>(smem + off); off += (size_t)n;
-    L.lp = reinterpret_cast<uint8_t*>(smem + off);      // unused (and empty) when K == 0
-    off = (off + (K ? (size_t)n : 0) + 15) & ~(size_t)15;
+    L.lp = reinterpret_cast<uint8_t*>(smem + off);
+    off = (off + (size_t)n + 15) & ~(size_t)15;
     L.cmd = reinterpret_cast<int*>(smem + off);         // NW > 1 only (greedy_lds)
     L.part = reinterpret_cast<Part*>(smem + off + 16);
     constexpr bool BIG = W == 16;
@@ -355,7 +381,7 @@ __global__ void __launch_bounds__(64 * NW) k_greedy(const double* __restrict__ K
         L.oend[i] = (uint16_t)i;
         L.nb[2 * i] = L.nb[2 * i + 1] = 0xffffu;
         L.deg[i] = 0;
-        if (K) L.lp[i] = 0;
+        L.lp[i] = 0;
         const size_t src = ((size_t)b * n + i) * kTopK;
         for (int p = 0; p < K; ++p) {
             L.lk[i * K + p] = lkey[src + p];
@@ -456,7 +482,8 @@ __global__ void __launch_bounds__(64 * NW) k_greedy(const double* __restrict__ K
             refresh_group<BIG>(L, n, i, lane, gm0, gm1, gm2);
             if ((j >> 6) != (i >> 6)) refresh_group<BIG>(L, n, j, lane, gm0, gm1, gm2);
         } else {
-            if (!advance(L, K, i, lane)) rescan<W, NW>(L, Kb, n, i, lane);
+            if (!advance(L, K, i, lane, lkey + (size_t)b * n * kTopK, lj0 + (size_t)b * n * kTopK))
+                rescan<W, NW>(L, Kb, n, i, lane);
             __builtin_amdgcn_wave_barrier();
             refresh_group<BIG>(L, n, i, lane, gm0, gm1, gm2);
         }
@@ -505,19 +532,21 @@ __global__ void __launch_bounds__(64 * NW) k_greedy(const double* __restrict__ K
 }
 
 constexpr int kGreedyListMaxN = 4500;   // lists of 2 fit the LDS of one wave's heat map up to here
-constexpr int kGreedyMaxN = 10800;      // 15 B of state per node in 160 KB; 169 groups of 64 nodes (<= 192)
+constexpr int kGreedyMaxN = 10200;      // 16 B of state per node in 160 KB; 160 groups of 64 nodes (<= 192)
 constexpr int kGreedyBigWaves = 16;     // waves per heat map above kGreedyListMaxN nodes
 
 // list entries per node (extracted by the prepare kernel and kept in LDS by the merge loop): kTopK
 // while a heat map's state stays near 64 KB; 2 for larger n; none above kGreedyListMaxN (the state of
-// a TSP-10000 map alone is 150 KB: every replacement is a row rescan); 1 (the row's best only) for small
+// a TSP-10000 map alone is 160 KB: the lists stay in global memory); 1 (the row's best only) for small
 // n, where tracking and extracting more costs the prepare kernel more than the merge loop gains
 inline int greedy_k(int n) { return n <= 128 ? 1 : n <= 1700 ? kTopK : n <= kGreedyListMaxN ? 2 : 0; }
+// entries the prepare kernel extracts per node
+inline int greedy_rounds(int n) { return greedy_k(n) ? greedy_k(n) : kTopK; }
 
 inline size_t greedy_lds(int n)
 {
     const int K = greedy_k(n);
-    return (size_t)n * (8 + 6 * (size_t)K + 2 + 4 + 1 + (K ? 1 : 0)) + 64 +
+    return (size_t)n * (8 + 6 * (size_t)K + 2 + 4 + 1 + 1) + 64 +
            (K ? 0 : 32 + sizeof(Part) * kGreedyBigWaves);
 }
 
@@ -551,10 +580,10 @@ int greedy_t(const void* heat, const double* points, int64_t* tours, int64_t num
     // grid.y is limited to 65535: prepare in slabs of heat maps
     for (int64_t b0 = 0; b0 < num_maps; b0 += 32768) {
         const dim3 grid((unsigned)((n + 31) / 32), (unsigned)std::min<int64_t>(32768, num_maps - b0), 1);
-        if (greedy_k(n) <= 1)       // the row's best only (it is also every node's first candidate when K = 0)
+        if (greedy_rounds(n) == 1)
             hipLaunchKernelGGL((k_greedy_prepare<H, 1>), grid, dim3(64, 8), 0, stream, A, points, Kd, lkey, lj, n, mpi, b0, 1);
         else
-            hipLaunchKernelGGL((k_greedy_prepare<H, 2>), grid, dim3(64, 8), 0, stream, A, points, Kd, lkey, lj, n, mpi, b0, greedy_k(n));
+            hipLaunchKernelGGL((k_greedy_prepare<H, 2>), grid, dim3(64, 8), 0, stream, A, points, Kd, lkey, lj, n, mpi, b0, greedy_rounds(n));
         HIP_TRY(hipGetLastError());
     }
     const size_t lds = greedy_lds(n);
@@ -585,7 +614,7 @@ extern "C" int tsp2opt_greedy_decode(const void* heat, const double* points, int
                                      int64_t workspace_bytes, void* hip_stream)
 {
     if (num_maps < 0 || n < 2 || maps_per_instance < 1) return fail(TSP2OPT_E_ARG, "bad size");
-    if (n > kGreedyMaxN) return fail(TSP2OPT_E_UNSUPPORTED, "greedy decode supports n <= 10800");
+    if (n > kGreedyMaxN) return fail(TSP2OPT_E_UNSUPPORTED, "greedy decode supports n <= 10200");
     if (heat_dtype != TSP2OPT_DTYPE_F32 && heat_dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
     if (num_maps == 0) return 0;
     if (!heat || !points || !tours_out || !workspace) return fail(TSP2OPT_E_ARG, "null pointer");
