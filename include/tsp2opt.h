@@ -76,7 +76,9 @@ extern "C" {
  *   dtype     TSP2OPT_DTYPE_F32 / _F64: dtype of `points` AND of the arithmetic
  *   device    HIP device ordinal that owns the buffers
  *   workspace / workspace_bytes  device scratch of at least tsp2opt_workspace_bytes(...) bytes,
- *            256-byte aligned; NULL: the library allocates and frees it on `hip_stream`
+ *            256-byte aligned; NULL: the library allocates and frees it on `hip_stream`.
+ *            Arrays must be aligned to their element size; misaligned pointers are rejected
+ *            (TSP2OPT_E_ARG) rather than left to fault in a kernel.
  *   hip_stream  hipStream_t to enqueue on (torch.cuda.current_stream(device).cuda_stream); the
  *            call is asynchronous with respect to the host
  *
@@ -128,7 +130,8 @@ int tsp2opt_evaluate(const void* points, const int64_t* tours, double* lengths_o
  *   points    (num_instances, n, 2) double (the reference casts to double, greedy_search.py:15)
  *   tours_out (num_maps, n+1) int64: tour from node 0 back to node 0
  *   maps_per_instance  heat map k belongs to instance k / maps_per_instance (parallel_sampling)
- *   workspace at least tsp2opt_greedy_workspace_bytes(...) bytes (holds A + A^T)
+ *   workspace at least tsp2opt_greedy_workspace_bytes(...) bytes, 256-byte aligned (holds the key
+ *            matrices and the candidate lists)
  * Edges are taken in increasing order of -A_ij/|v_i-v_j| (double); exactly equal keys of different
  * edges are ordered by flat index i*n+j (the reference's order for ties is numpy's unstable argsort:
  * undefined).  n <= 10200 (the state of one heat map, 16 B per node, lives in the LDS of one wave).

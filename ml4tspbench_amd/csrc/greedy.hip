@@ -621,6 +621,11 @@ extern "C" int tsp2opt_greedy_decode(const void* heat, const double* points, int
     if (workspace_bytes < tsp2opt_greedy_workspace_bytes(num_maps, n, heat_dtype))
         return fail(TSP2OPT_E_WORKSPACE, "workspace too small");
     if (num_maps > 0x7fffffffll) return fail(TSP2OPT_E_UNSUPPORTED, "too many heat maps");
+    if ((reinterpret_cast<uintptr_t>(heat) % (heat_dtype == TSP2OPT_DTYPE_F64 ? 8 : 4)) ||
+        (reinterpret_cast<uintptr_t>(points) % 8) || (reinterpret_cast<uintptr_t>(tours_out) % 8))
+        return fail(TSP2OPT_E_ARG, "misaligned pointer (arrays must be aligned to their element size)");
+    if (reinterpret_cast<uintptr_t>(workspace) % 256)
+        return fail(TSP2OPT_E_ARG, "workspace must be 256-byte aligned");
     DeviceGuard guard(device);
     if (!guard.ok) return fail(TSP2OPT_E_HIP, "hipSetDevice failed");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);

@@ -566,6 +566,14 @@ extern "C" int tsp2opt_solve(const void* points, int64_t* tours, int32_t* iters_
         return fail(TSP2OPT_E_ARG, "group_size must divide tours_per_instance and num_tours");
     if (dtype != TSP2OPT_DTYPE_F32 && dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
     if (max_iterations < 0) return fail(TSP2OPT_E_ARG, "max_iterations < 0");
+    // the kernels use naturally aligned vector accesses and atomics: a misaligned pointer would fault
+    const uintptr_t esz = dtype == TSP2OPT_DTYPE_F64 ? 8 : 4;
+    if ((reinterpret_cast<uintptr_t>(points) % esz) || (reinterpret_cast<uintptr_t>(tours) % 8) ||
+        (reinterpret_cast<uintptr_t>(iters_out) % 4) || (reinterpret_cast<uintptr_t>(sweeps_out) % 4) ||
+        (reinterpret_cast<uintptr_t>(status_out) % 4) || (reinterpret_cast<uintptr_t>(lengths_out) % 8))
+        return fail(TSP2OPT_E_ARG, "misaligned pointer (arrays must be aligned to their element size)");
+    if (reinterpret_cast<uintptr_t>(workspace) % 256)
+        return fail(TSP2OPT_E_ARG, "workspace must be 256-byte aligned");
     DeviceGuard guard(device);
     if (!guard.ok) return fail(TSP2OPT_E_HIP, "hipSetDevice failed");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
