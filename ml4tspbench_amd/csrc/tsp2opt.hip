@@ -116,8 +116,24 @@ int g_lcap16 = 13;          // diagnostic: changed-group list capacity of the cl
 int g_lcap16s = 13;         // changed-tile list capacity of the one-workgroup / full-window kernel, in 1/16 of the tiles
 int g_inc_min_tiles = 2;    // tile cache only when a lane owns at least this many tiles (measured: TSP-50 / TSP-100)
 
+Plan make_plan_nt(int n, int dtype, int cs, int nt_cap);
+
 // cs > 1: geometry of one workgroup of a full-window cluster of cs workgroups (lane groups interleaved)
 Plan make_plan(int n, int dtype, int cs = 1)
+{
+    Plan pl = make_plan_nt(n, dtype, cs, 1024);
+    // filter class 256 is compiled for at most 512 threads (kMaxThreads): the few N just above the
+    // 512 -> 1024 thread switch that still land in class 256 are planned with 512 threads, or moved to
+    // class 512 if that geometry no longer fits class 256
+    if (pl.g.qclass == 256 && pl.g.nt > 512) {
+        const Plan p2 = make_plan_nt(n, dtype, cs, 512);
+        pl = p2.g.qclass == 256 ? p2 : make_plan_nt(n, dtype, cs, -512);
+    }
+    return pl;
+}
+
+// nt_cap > 0: at most that many threads; nt_cap = -512: default threads, filter class at least 512
+Plan make_plan_nt(int n, int dtype, int cs, int nt_cap)
 {
     Plan pl{};
     Geo& g = pl.g;
@@ -131,6 +147,7 @@ Plan make_plan(int n, int dtype, int cs = 1)
     // threads per workgroup: about 500 pairs per lane per sweep
     int nt = n <= 160 ? 64 : n <= 320 ? 128 : n <= 640 ? 256 : n <= 1280 ? 512 : 1024;
     if (g_force_nt) nt = g_force_nt;
+    if (nt_cap > 0 && nt > nt_cap) nt = nt_cap;
     g.nt = nt;
     g.qclass = 0;
     size_t cache = 0;
@@ -154,6 +171,7 @@ Plan make_plan(int n, int dtype, int cs = 1)
             const int q = W / 8 + 1;
             for (int qc : kQClasses) {
                 if (W >= 3 * n) break;                  // wrap3(): window positions must stay below 3n
+                if (nt_cap < 0 && qc < -nt_cap) continue;
                 if (qc >= q && base + (size_t)qc * 192 <= kLdsMax) {
                     g.qclass = qc; g.GP = GP; g.G = G; g.NS = NS; g.MS = MS;
                     g.W = W;
@@ -191,6 +209,7 @@ template <typename T, int Q>
 int launch_main(const Params& p, const Plan& pl, int device, hipStream_t stream, int* blocks_per_cu)
 {
     auto kern = k_two_opt<T, Q, false>;
+    if (pl.g.nt > kMaxThreads<Q>) return fail(TSP2OPT_E_ARG, "internal: too many threads for this filter class");
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
     int per_cu = 0;
@@ -212,6 +231,7 @@ template <typename T, int Q>
 int launch_fw(Params p, const Plan& pl, int cus, hipStream_t stream)
 {
     auto kern = k_two_opt<T, Q, true>;
+    if (pl.g.nt > kMaxThreads<Q>) return fail(TSP2OPT_E_ARG, "internal: too many threads for this filter class");
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
     const int CS = pl.g.CS;

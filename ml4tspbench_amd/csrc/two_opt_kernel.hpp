@@ -713,8 +713,15 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t
 // finds the exact best move of its tiles, the cluster meets at cluster_exchange and everybody applies
 // the winner.  Clusters take tours statically (cluster, cluster + num_clusters, ...); the host
 // launches at most one workgroup per CU so that a cluster is co-resident.  Independent termination only.
+// Threads per workgroup by filter class.  Class 256 (N about 670..1340) fills a CU's LDS with one
+// workgroup of 512 threads = 2 waves per SIMD: bounding the launch at 512 gives the compiler 256 VGPRs
+// instead of 128 (no spills); the other classes need the 128-VGPR budget for their occupancy
+// (4 workgroups of 256 threads per CU at class 128) or run 1024 threads (class 512, exact kernel).
+template <int Q>
+constexpr int kMaxThreads = Q == 256 ? 512 : 1024;
+
 template <typename T, int Q, bool CL>
-__global__ void __launch_bounds__(1024) k_two_opt(Params p)
+__global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Geo g = p.g;
