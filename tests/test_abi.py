@@ -75,3 +75,16 @@ def test_plan_is_consistent():
                 assert 4 * NS * MS + 4 * G + 8 <= 8 * pl["filter_class"]   # window fits the LDS arrays
     with pytest.raises(_lib.Tsp2optError):
         _lib.plan(0)
+
+
+def test_filter_class_256_runs_512_threads():
+    """k_two_opt<.., 256, ..> is compiled for at most 512 threads (kMaxThreads): no plan may ask for more."""
+    from ml4tspbench_amd import _lib
+    seen = set()
+    for n in range(600, 1500):
+        for dt in (_lib.DTYPE_F32, _lib.DTYPE_F64):
+            pl = _lib.plan(n, dt, -1)
+            seen.add(pl["filter_class"])
+            if pl["filter_class"] == 256:
+                assert pl["threads"] <= 512, (n, pl)
+    assert {128, 256, 512} <= seen
