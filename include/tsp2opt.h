@@ -195,7 +195,8 @@ int tsp2opt_debug_cluster_inc(int32_t on);
  * changed-group list in sixteenths of all groups (default 13); what = 2: tiles a lane must own for the
  * tile-minimum cache to be used (default 2); what = 3: cluster kernel variant, 0 automatic, 1 band
  * kernel only, 2 full-window kernel only; what = 4: changed-tile list capacity of the one-workgroup /
- * full-window kernels in sixteenths of the tiles (default 13). */
+ * full-window kernels in sixteenths of the tiles (default 13); what = 5: unused LDS bytes added to the
+ * one-workgroup kernel's request (lowers the workgroups resident per CU: occupancy sweeps; default 0). */
 int tsp2opt_debug_tune(int32_t what, int32_t value);
 /* Geometry the library would pick for `num_tours` tours of n nodes on a device with `cus` compute
  * units when several workgroups share a tour (host-only, for logs and tests):

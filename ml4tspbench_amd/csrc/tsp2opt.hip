@@ -114,6 +114,7 @@ const int kQClasses[] = {16, 32, 64, 128, 256, 512};
 int g_force_nt = 0;         // diagnostic: threads per workgroup of the single-workgroup plan
 int g_lcap16 = 13;          // diagnostic: changed-group list capacity of the cluster kernel, in 1/16 of the groups
 int g_lcap16s = 13;         // changed-tile list capacity of the one-workgroup / full-window kernel, in 1/16 of the tiles
+int g_lds_pad = 0;           // diagnostic: unused LDS bytes added to the one-workgroup kernel's request (occupancy sweeps)
 int g_inc_min_tiles = 2;    // tile cache only when a lane owns at least this many tiles (measured: TSP-50 / TSP-100)
 
 Plan make_plan_nt(int n, int dtype, int cs, int nt_cap);
@@ -206,10 +207,12 @@ Plan make_plan_nt(int n, int dtype, int cs, int nt_cap)
 }
 
 template <typename T, int Q>
-int launch_main(const Params& p, const Plan& pl, int device, hipStream_t stream, int* blocks_per_cu)
+int launch_main(const Params& p, const Plan& plan, int device, hipStream_t stream, int* blocks_per_cu)
 {
     auto kern = k_two_opt<T, Q, false>;
-    if (pl.g.nt > kMaxThreads<Q>) return fail(TSP2OPT_E_ARG, "internal: too many threads for this filter class");
+    if (plan.g.nt > kMaxThreads<Q>) return fail(TSP2OPT_E_ARG, "internal: too many threads for this filter class");
+    Plan pl = plan;
+    if (g_lds_pad > 0 && pl.lds + (size_t)g_lds_pad <= kLdsMax) pl.lds += (size_t)g_lds_pad;    // diagnostic
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
     int per_cu = 0;
@@ -783,6 +786,7 @@ extern "C" int tsp2opt_debug_tune(int32_t what, int32_t value)
     else if (what == 2) g_inc_min_tiles = value;
     else if (what == 3) g_cluster_variant = value;
     else if (what == 4) g_lcap16s = value < 1 ? 1 : value > 16 ? 16 : value;
+    else if (what == 5) g_lds_pad = value < 0 ? 0 : value;
     else return fail(TSP2OPT_E_ARG, "unknown tuning knob");
     return 0;
 }
