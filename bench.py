@@ -53,6 +53,33 @@ def make_batch(name: str, seed: int, dtype):
     return pts.astype(dtype), tours, tpi
 
 
+def make_heat(pts: torch.Tensor, per: int, knn: int, seed: int) -> torch.Tensor:
+    """Synthetic heat maps for greedy-decoded start tours (no checkpoints exist offline): (I,N,2) float64
+    on the device -> (I*per, N, N) float32, exp(-d_ij / tau) times per-sample multiplicative noise, i.e.
+    "nearest edges are hot", which decodes to a reasonable but unoptimised tour -- the kind of start 2-opt
+    sees in the reference (BASELINE.json configs[0..3]).  knn > 0 zeroes everything outside each node's
+    knn nearest neighbours (configs[3]'s sparse k=50 heat map, densified as greedy_search.py:41-47 does)."""
+    inst, n, _ = pts.shape
+    g = torch.Generator(device=pts.device)
+    g.manual_seed(seed)
+    out = torch.empty((inst * per, n, n), dtype=torch.float32, device=pts.device)
+    tau = 0.35 / np.sqrt(n)
+    step = max(1, (1 << 26) // (n * n * per))
+    for a in range(0, inst, step):
+        p = pts[a:a + step]
+        d = torch.cdist(p, p)                                    # (c,N,N) float64
+        h = torch.exp(-d / tau).to(torch.float32)
+        if knn:
+            kth = d.topk(knn + 1, dim=-1, largest=False).values[..., -1:]
+            h = torch.where(d <= kth, h, torch.zeros_like(h))
+        h = h.repeat_interleave(per, dim=0)
+        noise = 0.6 + 0.8 * torch.rand(h.shape, generator=g, device=pts.device, dtype=torch.float32)
+        h = h * noise
+        h.diagonal(dim1=-2, dim2=-1).zero_()
+        out[a * per:(a + step) * per] = h
+    return out
+
+
 def cpu_baseline(name: str, pts: np.ndarray, tours: np.ndarray, tpi: int, group: int, cap: int):
     """The oracle (oracle/two_opt_oracle.c, a port of the reference algorithm) timed on this box's
     host cores on a bounded sample of the same workload (about 20 s of CPU work): the first `want`

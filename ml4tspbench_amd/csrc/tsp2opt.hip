@@ -50,6 +50,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "tsp2opt.h"
@@ -83,14 +84,62 @@ struct ProfSlot {
     long long calls = 0;                                        // profiled calls so far; current = (calls - 1) % ring
     ProfEntry& cur() { return ring[(calls > 0 ? calls - 1 : 0) % kProfRing]; }
 };
-int g_profile = 0;
-int g_dbg_sweeps = 0;                // diagnostic: filter sweeps only (tsp2opt_debug_sweep_only)
-int g_stamps = 0;                    // phase timers into workspace bytes [64, 128)
-ProfSlot g_prof[kMaxDev];
+// Test / diagnostic knobs (tsp2opt_debug_*, tsp2opt_profile_enable).  They belong to the CALLING THREAD:
+// a setter changes the calling thread's copy, and every entry point snapshots its own thread's copy once
+// on entry, so a knob flipped by one thread never changes a call running on another (one thread per
+// device is the supported concurrency).
+struct Opts {
+    int profile = 0;            // HIP events around the persistent kernel (tsp2opt_profile_enable)
+    int dbg_sweeps = 0;         // filter sweeps only (tsp2opt_debug_sweep_only)
+    int stamps = 0;             // phase timers into workspace bytes [64, 256)
+    int force_nt = 0;           // threads per workgroup of the single-workgroup plan
+    int lcap16 = 13;            // changed-group list capacity of the band cluster kernel, in 1/16 of the groups
+    int lcap16s = 13;           // changed-tile list capacity of the one-workgroup / full-window kernel, in 1/16 of the tiles
+    int lds_pad = 0;            // unused LDS bytes added to the one-workgroup kernel's request (occupancy sweeps)
+    int inc_min_tiles = 2;      // tile cache only when a lane owns at least this many tiles (measured: TSP-50 / TSP-100)
+    int cluster_inc = 1;        // 0: band cluster kernel without the group-minimum cache
+    int cluster_mode = -1;      // -1 auto, 0 never, >= 2 force that many workgroups per tour (tests)
+    int cluster_variant = 0;    // 0 auto, 1 band kernel only (k_two_opt_cluster), 2 full-window kernel only
+    int force_lockstep = 0;     // coupled mode: replay the whole call in k_group_lockstep (tests)
+};
+thread_local Opts t_opts;
 
-int prof_record(int device, int which, hipStream_t stream)
+ProfSlot g_prof[kMaxDev];
+std::mutex g_prof_mu[kMaxDev];      // the rings are per device, but any thread may read them
+
+// Cluster kernels (several workgroups per tour meeting at a spin barrier) need all their workgroups
+// resident at once.  The grid never exceeds what the device holds (checked at launch), and cluster
+// launches of this process on one device are chained through an event, so two of them issued on
+// different streams never share the CUs (each could otherwise hold slots the other waits for).
+struct ClusterChain {
+    std::mutex mu;
+    hipEvent_t ev = nullptr;
+    bool recorded = false;
+};
+ClusterChain g_chain[kMaxDev];
+
+int chain_begin(int device, hipStream_t stream)
 {
-    if (!g_profile || device < 0 || device >= kMaxDev) return 0;
+    if (device < 0 || device >= kMaxDev) return 0;
+    ClusterChain& c = g_chain[device];
+    if (!c.ev) HIP_TRY(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
+    if (c.recorded) HIP_TRY(hipStreamWaitEvent(stream, c.ev, 0));
+    return 0;
+}
+
+int chain_end(int device, hipStream_t stream)
+{
+    if (device < 0 || device >= kMaxDev) return 0;
+    ClusterChain& c = g_chain[device];
+    HIP_TRY(hipEventRecord(c.ev, stream));
+    c.recorded = true;
+    return 0;
+}
+
+int prof_record(const Opts& o, int device, int which, hipStream_t stream)
+{
+    if (!o.profile || device < 0 || device >= kMaxDev) return 0;
+    std::lock_guard<std::mutex> lk(g_prof_mu[device]);
     if (which == 0) {                                           // a new call: next ring entry
         ++g_prof[device].calls;
         g_prof[device].cur().have_main = g_prof[device].cur().have_forced = false;
@@ -98,6 +147,8 @@ int prof_record(int device, int which, hipStream_t stream)
     ProfEntry& s = g_prof[device].cur();
     if (!s.ev[which]) HIP_TRY(hipEventCreate(&s.ev[which]));
     HIP_TRY(hipEventRecord(s.ev[which], stream));
+    if (which == 1) s.have_main = true;
+    if (which == 3) s.have_forced = true;
     return 0;
 }
 
@@ -111,30 +162,25 @@ constexpr size_t kLdsMax = 160 * 1024;
 constexpr size_t kCsyncBytes = 64 * 1024;   // cluster barrier words + slots (<= 256 workgroups)
 const int kQClasses[] = {16, 32, 64, 128, 256, 512};
 
-int g_force_nt = 0;         // diagnostic: threads per workgroup of the single-workgroup plan
-int g_lcap16 = 13;          // diagnostic: changed-group list capacity of the cluster kernel, in 1/16 of the groups
-int g_lcap16s = 13;         // changed-tile list capacity of the one-workgroup / full-window kernel, in 1/16 of the tiles
-int g_lds_pad = 0;           // diagnostic: unused LDS bytes added to the one-workgroup kernel's request (occupancy sweeps)
-int g_inc_min_tiles = 2;    // tile cache only when a lane owns at least this many tiles (measured: TSP-50 / TSP-100)
 
-Plan make_plan_nt(int n, int dtype, int cs, int nt_cap);
+Plan make_plan_nt(const Opts& o, int n, int dtype, int cs, int nt_cap);
 
 // cs > 1: geometry of one workgroup of a full-window cluster of cs workgroups (lane groups interleaved)
-Plan make_plan(int n, int dtype, int cs = 1)
+Plan make_plan(const Opts& o, int n, int dtype, int cs = 1)
 {
-    Plan pl = make_plan_nt(n, dtype, cs, 1024);
+    Plan pl = make_plan_nt(o, n, dtype, cs, 1024);
     // filter class 256 is compiled for at most 512 threads (kMaxThreads): the few N just above the
     // 512 -> 1024 thread switch that still land in class 256 are planned with 512 threads, or moved to
     // class 512 if that geometry no longer fits class 256
     if (pl.g.qclass == 256 && pl.g.nt > 512) {
-        const Plan p2 = make_plan_nt(n, dtype, cs, 512);
-        pl = p2.g.qclass == 256 ? p2 : make_plan_nt(n, dtype, cs, -512);
+        const Plan p2 = make_plan_nt(o, n, dtype, cs, 512);
+        pl = p2.g.qclass == 256 ? p2 : make_plan_nt(o, n, dtype, cs, -512);
     }
     return pl;
 }
 
 // nt_cap > 0: at most that many threads; nt_cap = -512: default threads, filter class at least 512
-Plan make_plan_nt(int n, int dtype, int cs, int nt_cap)
+Plan make_plan_nt(const Opts& o, int n, int dtype, int cs, int nt_cap)
 {
     Plan pl{};
     Geo& g = pl.g;
@@ -147,7 +193,7 @@ Plan make_plan_nt(int n, int dtype, int cs, int nt_cap)
     const size_t xbytes = (size_t)n * 2 * tsz;
     // threads per workgroup: about 500 pairs per lane per sweep
     int nt = n <= 160 ? 64 : n <= 320 ? 128 : n <= 640 ? 256 : n <= 1280 ? 512 : 1024;
-    if (g_force_nt) nt = g_force_nt;
+    if (o.force_nt) nt = o.force_nt;
     if (nt_cap > 0 && nt > nt_cap) nt = nt_cap;
     g.nt = nt;
     g.qclass = 0;
@@ -184,9 +230,9 @@ Plan make_plan_nt(int n, int dtype, int cs, int nt_cap)
                 // minimum cache (4 B per tile) + changed-tile list (2 B per entry, 13/16 of the tiles: measured
                 // on TSP-100/500/1000, beyond that a plain sweep is cheaper than recomputing tile by tile)
                 const size_t tiles = (size_t)GPl * NS * (MS / 2);
-                const size_t lcap = tiles * (size_t)g_lcap16s / 16 + 1;
+                const size_t lcap = tiles * (size_t)o.lcap16s / 16 + 1;
                 const size_t need = align16(4 * tiles) + align16(2 * lcap);
-                if (MS / 2 >= g_inc_min_tiles && (size_t)NS * (MS / 2) <= 255 && GPl <= 255 && MS / 2 <= 32 && GPl * NS <= nt &&
+                if (MS / 2 >= o.inc_min_tiles && (size_t)NS * (MS / 2) <= 255 && GPl <= 255 && MS / 2 <= 32 && GPl * NS <= nt &&
                     base + (size_t)g.qclass * 192 + need <= kLdsMax) {
                     g.inc = 1;
                     g.lcap = (int)lcap;
@@ -207,12 +253,12 @@ Plan make_plan_nt(int n, int dtype, int cs, int nt_cap)
 }
 
 template <typename T, int Q>
-int launch_main(const Params& p, const Plan& plan, int device, hipStream_t stream, int* blocks_per_cu)
+int launch_main(const Opts& o, const Params& p, const Plan& plan, int device, hipStream_t stream, int* blocks_per_cu)
 {
     auto kern = k_two_opt<T, Q, false>;
     if (plan.g.nt > kMaxThreads<Q>) return fail(TSP2OPT_E_ARG, "internal: too many threads for this filter class");
     Plan pl = plan;
-    if (g_lds_pad > 0 && pl.lds + (size_t)g_lds_pad <= kLdsMax) pl.lds += (size_t)g_lds_pad;    // diagnostic
+    if (o.lds_pad > 0 && pl.lds + (size_t)o.lds_pad <= kLdsMax) pl.lds += (size_t)o.lds_pad;    // diagnostic
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
     int per_cu = 0;
@@ -231,12 +277,15 @@ int launch_main(const Params& p, const Plan& plan, int device, hipStream_t strea
 
 // full-window cluster: `clusters` x CS workgroups, at most one per CU (co-residency)
 template <typename T, int Q>
-int launch_fw(Params p, const Plan& pl, int cus, hipStream_t stream)
+int launch_fw(Params p, const Plan& pl, int cus, int device, hipStream_t stream)
 {
     auto kern = k_two_opt<T, Q, true>;
     if (pl.g.nt > kMaxThreads<Q>) return fail(TSP2OPT_E_ARG, "internal: too many threads for this filter class");
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, pl.g.nt, pl.lds));
+    if (per_cu < 1) return fail(TSP2OPT_E_UNSUPPORTED, "internal: cluster workgroup does not fit a CU");
     const int CS = pl.g.CS;
     int clusters = cus / CS;
     if (clusters > p.num_tours) clusters = (int)p.num_tours;
@@ -245,33 +294,36 @@ int launch_fw(Params p, const Plan& pl, int cus, hipStream_t stream)
     p.cstride = ((16 + 2 * CS * kSlotDw) + 63) & ~63;
     if ((size_t)clusters * (size_t)p.cstride * 4 > kCsyncBytes)
         return fail(TSP2OPT_E_UNSUPPORTED, "internal: cluster sync area too small");
+    std::lock_guard<std::mutex> lk(g_chain[device < kMaxDev ? device : 0].mu);
+    int rc = chain_begin(device, stream);       // after the previous cluster launch on this device
+    if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)(clusters * CS)), dim3((unsigned)pl.g.nt), pl.lds, stream, p);
     HIP_TRY(hipGetLastError());
-    return 0;
+    return chain_end(device, stream);
 }
 
 template <typename T>
-int dispatch_fw(const Params& p, const Plan& pl, int cus, hipStream_t stream)
+int dispatch_fw(const Params& p, const Plan& pl, int cus, int device, hipStream_t stream)
 {
     switch (pl.g.qclass) {
-    case 128: return launch_fw<T, 128>(p, pl, cus, stream);
-    case 256: return launch_fw<T, 256>(p, pl, cus, stream);
-    case 512: return launch_fw<T, 512>(p, pl, cus, stream);
+    case 128: return launch_fw<T, 128>(p, pl, cus, device, stream);
+    case 256: return launch_fw<T, 256>(p, pl, cus, device, stream);
+    case 512: return launch_fw<T, 512>(p, pl, cus, device, stream);
     }
     return fail(TSP2OPT_E_ARG, "internal: no full-window cluster kernel for this filter class");
 }
 
 template <typename T>
-int dispatch_main(const Params& p, const Plan& pl, int device, hipStream_t stream, int* bpc = nullptr)
+int dispatch_main(const Opts& o, const Params& p, const Plan& pl, int device, hipStream_t stream, int* bpc = nullptr)
 {
     switch (pl.g.qclass) {
-    case 0: return launch_main<T, 0>(p, pl, device, stream, bpc);
-    case 16: return launch_main<T, 16>(p, pl, device, stream, bpc);
-    case 32: return launch_main<T, 32>(p, pl, device, stream, bpc);
-    case 64: return launch_main<T, 64>(p, pl, device, stream, bpc);
-    case 128: return launch_main<T, 128>(p, pl, device, stream, bpc);
-    case 256: return launch_main<T, 256>(p, pl, device, stream, bpc);
-    case 512: return launch_main<T, 512>(p, pl, device, stream, bpc);
+    case 0: return launch_main<T, 0>(o, p, pl, device, stream, bpc);
+    case 16: return launch_main<T, 16>(o, p, pl, device, stream, bpc);
+    case 32: return launch_main<T, 32>(o, p, pl, device, stream, bpc);
+    case 64: return launch_main<T, 64>(o, p, pl, device, stream, bpc);
+    case 128: return launch_main<T, 128>(o, p, pl, device, stream, bpc);
+    case 256: return launch_main<T, 256>(o, p, pl, device, stream, bpc);
+    case 512: return launch_main<T, 512>(o, p, pl, device, stream, bpc);
     }
     return fail(TSP2OPT_E_ARG, "internal: bad filter class");
 }
@@ -305,9 +357,8 @@ struct CPlan {
 };
 
 // geometry of the cluster kernel for at most `cs_cap` workgroups per tour
-int g_cluster_inc = 1;      // 0: cluster kernel without the group-minimum cache (diagnostic)
 
-CPlan make_cluster_plan(int n, int dtype, int cs_cap, bool smallest)
+CPlan make_cluster_plan(const Opts& o, int n, int dtype, int cs_cap, bool smallest)
 {
     CPlan best{};
     best.ok = false;
@@ -347,11 +398,11 @@ CPlan make_cluster_plan(int n, int dtype, int cs_cap, bool smallest)
                 // group-minimum cache: the finest granularity K (macro steps per entry) that fits
                 int K = 0, Ksh = 0, NG = MS, lcap = 0;
                 size_t cache = 0;
-                if (units <= nt && g_cluster_inc) {
+                if (units <= nt && o.cluster_inc) {
                     for (int k = 1, sh = 2; k <= 64; k *= 2, ++sh) {
                         const int ng = (MS + k - 1) / k;
                         const size_t groups = (size_t)units * ng;
-                        const size_t cap = groups * (size_t)g_lcap16 / 16 + 1;
+                        const size_t cap = groups * (size_t)o.lcap16 / 16 + 1;
                         const size_t need = align16(4 * groups) + align16(2 * cap);
                         if (ng <= 64 && (size_t)nt * ng <= 65535 && lds + need <= kLdsMax) {
                             K = k; Ksh = sh; NG = ng; lcap = (int)cap; cache = need;
@@ -380,11 +431,14 @@ CPlan make_cluster_plan(int n, int dtype, int cs_cap, bool smallest)
 }
 
 template <typename T, int MAXNT>
-int launch_cluster(CParams p, const CPlan& cp, int cus, hipStream_t stream)
+int launch_cluster(CParams p, const CPlan& cp, int cus, int device, hipStream_t stream)
 {
     auto kern = k_two_opt_cluster<T, MAXNT>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp.lds));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, cp.g.nt, cp.lds));
+    if (per_cu < 1) return fail(TSP2OPT_E_UNSUPPORTED, "internal: cluster workgroup does not fit a CU");
     int clusters = cus / cp.g.CS;                       // one workgroup per CU: all co-resident
     if (clusters > p.num_tours) clusters = (int)p.num_tours;
     if (clusters < 1) return fail(TSP2OPT_E_UNSUPPORTED, "cluster does not fit the device");
@@ -392,15 +446,16 @@ int launch_cluster(CParams p, const CPlan& cp, int cus, hipStream_t stream)
     p.cstride = ((16 + 2 * cp.g.CS * kSlotDw) + 63) & ~63;
     if ((size_t)clusters * (size_t)p.cstride * 4 > kCsyncBytes)
         return fail(TSP2OPT_E_UNSUPPORTED, "internal: cluster sync area too small");
+    std::lock_guard<std::mutex> lk(g_chain[device < kMaxDev ? device : 0].mu);
+    int rc = chain_begin(device, stream);       // after the previous cluster launch on this device
+    if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)(clusters * cp.g.CS)), dim3((unsigned)cp.g.nt), cp.lds,
                        stream, p);
     HIP_TRY(hipGetLastError());
-    return 0;
+    return chain_end(device, stream);
 }
 
-int g_cluster_mode = -1;    // -1 auto, 0 never, >= 2 force that many workgroups per tour (tests)
 
-int g_cluster_variant = 0;  // 0 auto, 1 band kernel only (k_two_opt_cluster), 2 full-window kernel only
 
 // Several workgroups per tour?  kind 0: no (one workgroup per tour), 1: band cluster
 // (k_two_opt_cluster, any N), 2: full-window cluster (k_two_opt<.., true>, N within the fast path).
@@ -410,23 +465,23 @@ struct ClusterChoice {
     Plan fw;
 };
 
-ClusterChoice choose_cluster(int n, int dtype, int64_t num_tours, int cus, const Plan& pl)
+ClusterChoice choose_cluster(const Opts& o, int n, int dtype, int64_t num_tours, int cus, const Plan& pl)
 {
     ClusterChoice c{};
     c.kind = 0;
     int cap = (int)std::min<int64_t>(64, cus / std::max<int64_t>(1, num_tours));
-    const bool forced = g_cluster_mode >= 2;
-    if (forced) cap = std::min(g_cluster_mode, cus);
+    const bool forced = o.cluster_mode >= 2;
+    if (forced) cap = std::min(o.cluster_mode, cus);
     // full-window cluster: needs the fast path (and one of the instantiated filter classes) with the
     // whole window in LDS; at least 4 lane groups per workgroup
-    if (g_cluster_variant != 1 && cap >= 2 && pl.g.qclass != 0 && (forced || n >= 700)) {
+    if (o.cluster_variant != 1 && cap >= 2 && pl.g.qclass != 0 && (forced || n >= 700)) {
         const int cs = std::min(cap, std::max(1, pl.g.GP / 4));
         if (cs >= 2) {
-            const Plan fw = make_plan(n, dtype, cs);
+            const Plan fw = make_plan(o, n, dtype, cs);
             if (fw.g.qclass >= 128) { c.kind = 2; c.fw = fw; return c; }
         }
     }
-    if (g_cluster_variant == 2) return c;
+    if (o.cluster_variant == 2) return c;
     bool smallest = false;
     if (!forced) {
         if (pl.g.qclass == 0 && cap < 2) { cap = 64; smallest = true; }        // tiling for LDS only
@@ -434,18 +489,18 @@ ClusterChoice choose_cluster(int n, int dtype, int64_t num_tours, int cus, const
         // (small tours are not worth a barrier; with two band workgroups per tour the one-workgroup
         //  kernel with its finer incremental sweeps is faster even on half the CUs)
     }
-    c.band = make_cluster_plan(n, dtype, cap, smallest);
+    c.band = make_cluster_plan(o, n, dtype, cap, smallest);
     if (c.band.ok) c.kind = 1;
     return c;
 }
 
 template <typename T>
-int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* sweeps_out,
+int solve_t(const Opts& o, const void* points, int64_t* tours, int32_t* iters_out, int32_t* sweeps_out,
             double* lengths_out, int32_t* status_out, int64_t num_tours, int n, int tpi,
             int group_size, int max_iter, double time_limit_s, int dtype, int device, void* ws,
             hipStream_t stream)
 {
-    const Plan pl = make_plan(n, dtype);
+    const Plan pl = make_plan(o, n, dtype);
     const WsLayout wl = ws_layout(num_tours, group_size);
     unsigned char* w8 = static_cast<unsigned char*>(ws);
     Params p{};
@@ -463,10 +518,13 @@ int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* swe
     p.max_iter = max_iter;
     p.mode = kModeIndep;
     p.time_limit_ticks = 0;
-    p.stamps = g_stamps ? reinterpret_cast<unsigned long long*>(w8 + 64) : nullptr;
-    p.dbg_sweeps = g_dbg_sweeps;
+    p.stamps = o.stamps ? reinterpret_cast<unsigned long long*>(w8 + 64) : nullptr;
+    p.dbg_sweeps = o.dbg_sweeps;
     p.g = pl.g;
-    if (time_limit_s > 0.0 && group_size == 1) {
+    // test knob: coupled mode replayed entirely by k_group_lockstep (phase 1 only validates the tours)
+    const bool lockstep_only = group_size > 1 && o.force_lockstep != 0;
+    if (lockstep_only) p.mode = kModeValidate;
+    if (time_limit_s > 0.0) {
         int khz = 0;
         HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device));
         if (khz <= 0) khz = 100000;
@@ -478,15 +536,15 @@ int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* swe
     HIP_TRY(hipMemsetAsync(w8, 0, 256, stream));
     HIP_TRY(hipMemsetAsync(w8 + wl.off_work, 0, (size_t)num_tours * 4 + 4, stream));
     if (num_tours == 0) return 0;
-    int rc = prof_record(device, 0, stream);
+    int rc = prof_record(o, device, 0, stream);
     if (rc) return rc;
     // few tours (or N beyond one workgroup's LDS): several workgroups per tour
     ClusterChoice cc{};
     cc.kind = 0;
-    if (group_size == 1 && g_cluster_mode != 0 && g_dbg_sweeps == 0) {
+    if (group_size == 1 && o.cluster_mode != 0 && o.dbg_sweeps == 0) {
         int cus = 0;
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-        cc = choose_cluster(n, dtype, num_tours, cus, pl);
+        cc = choose_cluster(o, n, dtype, num_tours, cus, pl);
         if (cc.kind != 0) HIP_TRY(hipMemsetAsync(w8 + wl.off_csync, 0, kCsyncBytes, stream));
         if (cc.kind == 1) {
             const CPlan& cp = cc.band;
@@ -496,24 +554,23 @@ int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* swe
             c.num_tours = num_tours; c.tpi = tpi; c.max_iter = max_iter;
             c.time_limit_ticks = p.time_limit_ticks; c.g = cp.g;
             c.stamps = p.stamps;
-            rc = cp.g.nt <= 512 ? launch_cluster<T, 512>(c, cp, cus, stream)
-                                : launch_cluster<T, 768>(c, cp, cus, stream);
+            rc = cp.g.nt <= 512 ? launch_cluster<T, 512>(c, cp, cus, device, stream)
+                                : launch_cluster<T, 768>(c, cp, cus, device, stream);
             if (rc) return rc;
         } else if (cc.kind == 2) {
             Params pc = p;
             pc.g = cc.fw.g;
             pc.csync = reinterpret_cast<unsigned*>(w8 + wl.off_csync);
-            rc = dispatch_fw<T>(pc, cc.fw, cus, stream);
+            rc = dispatch_fw<T>(pc, cc.fw, cus, device, stream);
             if (rc) return rc;
         }
     }
     if (cc.kind == 0) {
-        rc = dispatch_main<T>(p, pl, device, stream);
+        rc = dispatch_main<T>(o, p, pl, device, stream);
         if (rc) return rc;
     }
-    rc = prof_record(device, 1, stream);
+    rc = prof_record(o, device, 1, stream);
     if (rc) return rc;
-    if (g_profile && device < kMaxDev) g_prof[device].cur().have_main = true;
     const unsigned tb = 256;
     const unsigned tgrid = (unsigned)((num_tours + tb - 1) / tb);
     if (group_size > 1) {
@@ -524,13 +581,14 @@ int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* swe
         HIP_TRY(hipGetLastError());
         Params pf = p;
         pf.mode = kModeForced;
-        rc = prof_record(device, 2, stream);
-        if (rc) return rc;
-        rc = dispatch_main<T>(pf, pl, device, stream);
-        if (rc) return rc;
-        rc = prof_record(device, 3, stream);
-        if (rc) return rc;
-        if (g_profile && device < kMaxDev) g_prof[device].cur().have_forced = true;
+        if (!lockstep_only) {
+            rc = prof_record(o, device, 2, stream);
+            if (rc) return rc;
+            rc = dispatch_main<T>(o, pf, pl, device, stream);
+            if (rc) return rc;
+            rc = prof_record(o, device, 3, stream);
+            if (rc) return rc;
+        }
         const int lnt = n <= 256 ? 256 : 1024;
         const size_t llds = align16(sizeof(Ctl)) + align16(sizeof(uint16_t) * (size_t)(n + 1)) +
                             align16(sizeof(unsigned) * (size_t)group_size);
@@ -538,7 +596,7 @@ int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* swe
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_lockstep<T>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
         hipLaunchKernelGGL(k_group_lockstep<T>, dim3((unsigned)groups), dim3(lnt), llds, stream, pf,
-                           target, 0);
+                           target, lockstep_only ? 1 : 0);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_group_finish, dim3(tgrid), dim3(tb), 0, stream, iters_out, sweeps_out,
                            p.status, target, num_tours, group_size, max_iter);
@@ -555,6 +613,48 @@ int solve_t(const void* points, int64_t* tours, int32_t* iters_out, int32_t* swe
         HIP_TRY(hipGetLastError());
     }
     return 0;
+}
+
+// argument checks shared by tsp2opt_solve and tsp2opt_solve_noalloc (no HIP call)
+int check_solve_args(const void* points, const int64_t* tours, const int32_t* iters_out,
+                     const int32_t* sweeps_out, const double* lengths_out, const int32_t* status_out,
+                     int64_t num_tours, int32_t n, int32_t tours_per_instance, int32_t group_size,
+                     int32_t max_iterations, double time_limit_s, int32_t dtype)
+{
+    if (num_tours < 0 || n < 1) return fail(TSP2OPT_E_ARG, "num_tours < 0 or n < 1");
+    if (num_tours > 0 && (!points || !tours)) return fail(TSP2OPT_E_ARG, "null points/tours");
+    if (n > TSP2OPT_MAX_N) return fail(TSP2OPT_E_UNSUPPORTED, "n > 65535 is not supported");
+    if (tours_per_instance < 1 || group_size < 1) return fail(TSP2OPT_E_ARG, "tours_per_instance/group_size < 1");
+    if (tours_per_instance % group_size != 0 || num_tours % group_size != 0)
+        return fail(TSP2OPT_E_ARG, "group_size must divide tours_per_instance and num_tours");
+    if (dtype != TSP2OPT_DTYPE_F32 && dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
+    if (max_iterations < 0) return fail(TSP2OPT_E_ARG, "max_iterations < 0");
+    // the reference has a wall-clock limit only in the plugin, whose batch is one tour
+    // (nar/local_search/two_opt.py:33,63-65); the coupled legacy call has none
+    if (time_limit_s > 0.0 && group_size > 1)
+        return fail(TSP2OPT_E_ARG, "time_limit_s needs group_size == 1 (the coupled call has no time limit)");
+    // the kernels use naturally aligned vector accesses and atomics: a misaligned pointer would fault
+    const uintptr_t esz = dtype == TSP2OPT_DTYPE_F64 ? 8 : 4;
+    if ((reinterpret_cast<uintptr_t>(points) % esz) || (reinterpret_cast<uintptr_t>(tours) % 8) ||
+        (reinterpret_cast<uintptr_t>(iters_out) % 4) || (reinterpret_cast<uintptr_t>(sweeps_out) % 4) ||
+        (reinterpret_cast<uintptr_t>(status_out) % 4) || (reinterpret_cast<uintptr_t>(lengths_out) % 8))
+        return fail(TSP2OPT_E_ARG, "misaligned pointer (arrays must be aligned to their element size)");
+    return 0;
+}
+
+int solve_any(const Opts& o, const void* points, int64_t* tours, int32_t* iters_out, int32_t* sweeps_out,
+              double* lengths_out, int32_t* status_out, int64_t num_tours, int32_t n, int32_t tpi,
+              int32_t group_size, int32_t max_iterations, double time_limit_s, int32_t dtype, int32_t device,
+              void* ws, hipStream_t stream)
+{
+    // two_opt.py:40-48: the first sweep still runs and, if it finds an improvement, is applied
+    // before the cap is tested; a cap of 0 therefore behaves like a cap of 1.
+    if (max_iterations == 0) max_iterations = 1;
+    if (dtype == TSP2OPT_DTYPE_F64)
+        return solve_t<double>(o, points, tours, iters_out, sweeps_out, lengths_out, status_out, num_tours,
+                               n, tpi, group_size, max_iterations, time_limit_s, dtype, device, ws, stream);
+    return solve_t<float>(o, points, tours, iters_out, sweeps_out, lengths_out, status_out, num_tours,
+                          n, tpi, group_size, max_iterations, time_limit_s, dtype, device, ws, stream);
 }
 
 }  // namespace t2o
@@ -581,20 +681,10 @@ extern "C" int tsp2opt_solve(const void* points, int64_t* tours, int32_t* iters_
                              int32_t dtype, int32_t device, void* workspace, int64_t workspace_bytes,
                              void* hip_stream)
 {
-    if (num_tours < 0 || n < 1) return fail(TSP2OPT_E_ARG, "num_tours < 0 or n < 1");
-    if (num_tours > 0 && (!points || !tours)) return fail(TSP2OPT_E_ARG, "null points/tours");
-    if (n > TSP2OPT_MAX_N) return fail(TSP2OPT_E_UNSUPPORTED, "n > 65535 is not supported");
-    if (tours_per_instance < 1 || group_size < 1) return fail(TSP2OPT_E_ARG, "tours_per_instance/group_size < 1");
-    if (tours_per_instance % group_size != 0 || num_tours % group_size != 0)
-        return fail(TSP2OPT_E_ARG, "group_size must divide tours_per_instance and num_tours");
-    if (dtype != TSP2OPT_DTYPE_F32 && dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
-    if (max_iterations < 0) return fail(TSP2OPT_E_ARG, "max_iterations < 0");
-    // the kernels use naturally aligned vector accesses and atomics: a misaligned pointer would fault
-    const uintptr_t esz = dtype == TSP2OPT_DTYPE_F64 ? 8 : 4;
-    if ((reinterpret_cast<uintptr_t>(points) % esz) || (reinterpret_cast<uintptr_t>(tours) % 8) ||
-        (reinterpret_cast<uintptr_t>(iters_out) % 4) || (reinterpret_cast<uintptr_t>(sweeps_out) % 4) ||
-        (reinterpret_cast<uintptr_t>(status_out) % 4) || (reinterpret_cast<uintptr_t>(lengths_out) % 8))
-        return fail(TSP2OPT_E_ARG, "misaligned pointer (arrays must be aligned to their element size)");
+    const Opts o = t_opts;
+    int rc = check_solve_args(points, tours, iters_out, sweeps_out, lengths_out, status_out, num_tours, n,
+                              tours_per_instance, group_size, max_iterations, time_limit_s, dtype);
+    if (rc) return rc;
     if (reinterpret_cast<uintptr_t>(workspace) % 256)
         return fail(TSP2OPT_E_ARG, "workspace must be 256-byte aligned");
     DeviceGuard guard(device);
@@ -609,20 +699,8 @@ extern "C" int tsp2opt_solve(const void* points, int64_t* tours, int32_t* iters_
     } else if ((size_t)workspace_bytes < need) {
         return fail(TSP2OPT_E_WORKSPACE, "workspace too small");
     }
-    int rc;
-    if (max_iterations == 0) {
-        // two_opt.py:40-48: the first sweep still runs and, if it finds an improvement, is applied
-        // before the cap is tested; a cap of 0 therefore behaves like a cap of 1.
-        max_iterations = 1;
-    }
-    if (dtype == TSP2OPT_DTYPE_F64)
-        rc = solve_t<double>(points, tours, iters_out, sweeps_out, lengths_out, status_out, num_tours,
-                             n, tours_per_instance, group_size, max_iterations, time_limit_s, dtype,
-                             device, ws, stream);
-    else
-        rc = solve_t<float>(points, tours, iters_out, sweeps_out, lengths_out, status_out, num_tours,
-                            n, tours_per_instance, group_size, max_iterations, time_limit_s, dtype,
-                            device, ws, stream);
+    rc = solve_any(o, points, tours, iters_out, sweeps_out, lengths_out, status_out, num_tours, n,
+                   tours_per_instance, group_size, max_iterations, time_limit_s, dtype, device, ws, stream);
     if (own) {
         (void)hipStreamSynchronize(stream);
         (void)hipFree(ws);
@@ -714,7 +792,7 @@ extern "C" int tsp2opt_sqrt_check(const void* in, void* out, int64_t count, int3
 
 extern "C" int tsp2opt_profile_enable(int32_t on)
 {
-    g_profile = on ? 1 : 0;
+    t_opts.profile = on ? 1 : 0;
     return 0;
 }
 
@@ -722,6 +800,7 @@ extern "C" int tsp2opt_profile_history_ms(int32_t device, int32_t calls_back, do
 {
     if (device < 0 || device >= kMaxDev || !main_ms || calls_back < 0 || calls_back >= kProfRing)
         return fail(TSP2OPT_E_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(g_prof_mu[device]);
     ProfSlot& slot = g_prof[device];
     if (slot.calls - calls_back < 1) return fail(TSP2OPT_E_ARG, "no such profiled call on this device");
     ProfEntry& s = slot.ring[(slot.calls - 1 - calls_back) % kProfRing];
@@ -750,10 +829,10 @@ extern "C" int tsp2opt_profile_last_ms(int32_t device, double* main_ms, double* 
 
 // Diagnostic: with on != 0, wave 0 lane 0 of every workgroup accumulates shader-clock cycles per
 // phase (filter sweep, argmin selection incl. exact re-evaluation, reversal, staging, whole tour)
-// into workspace bytes [64,104); read them back with tsp2opt_debug_read_phase_cycles after a sync.
+// into workspace bytes [64,104); read them back from the workspace after a sync.
 extern "C" int tsp2opt_debug_phase_cycles(int32_t on)
 {
-    g_stamps = on ? 1 : 0;
+    t_opts.stamps = on ? 1 : 0;
     return 0;
 }
 
@@ -761,7 +840,7 @@ extern "C" int tsp2opt_debug_phase_cycles(int32_t on)
 // selection, no reversal; tours come back unchanged, iters_out = sweeps).  Measures the hot loop alone.
 extern "C" int tsp2opt_debug_sweep_only(int32_t sweeps)
 {
-    g_dbg_sweeps = sweeps > 0 ? sweeps : 0;
+    t_opts.dbg_sweeps = sweeps > 0 ? sweeps : 0;
     return 0;
 }
 
@@ -769,36 +848,39 @@ extern "C" int tsp2opt_debug_sweep_only(int32_t sweeps)
 // workgroups per tour, 0 never cluster, k >= 2 use up to k workgroups per tour whenever possible.
 extern "C" int tsp2opt_debug_cluster_mode(int32_t mode)
 {
-    g_cluster_mode = mode;
+    t_opts.cluster_mode = mode;
     return 0;
 }
 
 extern "C" int tsp2opt_debug_cluster_inc(int32_t on)
 {
-    g_cluster_inc = on ? 1 : 0;
+    t_opts.cluster_inc = on ? 1 : 0;
     return 0;
 }
 
 extern "C" int tsp2opt_debug_tune(int32_t what, int32_t value)
 {
-    if (what == 0) g_force_nt = value;
-    else if (what == 1) g_lcap16 = value < 1 ? 1 : value > 16 ? 16 : value;
-    else if (what == 2) g_inc_min_tiles = value;
-    else if (what == 3) g_cluster_variant = value;
-    else if (what == 4) g_lcap16s = value < 1 ? 1 : value > 16 ? 16 : value;
-    else if (what == 5) g_lds_pad = value < 0 ? 0 : value;
+    Opts& o = t_opts;
+    if (what == 0) o.force_nt = value;
+    else if (what == 1) o.lcap16 = value < 1 ? 1 : value > 16 ? 16 : value;
+    else if (what == 2) o.inc_min_tiles = value;
+    else if (what == 3) o.cluster_variant = value;
+    else if (what == 4) o.lcap16s = value < 1 ? 1 : value > 16 ? 16 : value;
+    else if (what == 5) o.lds_pad = value < 0 ? 0 : value;
+    else if (what == 6) o.force_lockstep = value ? 1 : 0;
     else return fail(TSP2OPT_E_ARG, "unknown tuning knob");
     return 0;
 }
 
 extern "C" int tsp2opt_cluster_plan(int32_t n, int32_t dtype, int64_t num_tours, int32_t cus, int32_t* out12)
 {
+    const Opts o = t_opts;
     if (n < 1 || n > TSP2OPT_MAX_N || num_tours < 1 || cus < 1 || !out12) return fail(TSP2OPT_E_ARG, "bad argument");
     if (dtype != TSP2OPT_DTYPE_F32 && dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
-    const Plan pl = make_plan(n, dtype);
+    const Plan pl = make_plan(o, n, dtype);
     for (int k = 0; k < 12; ++k) out12[k] = 0;
-    if (g_cluster_mode == 0) return 0;
-    const ClusterChoice cc = choose_cluster(n, dtype, num_tours, cus, pl);
+    if (o.cluster_mode == 0) return 0;
+    const ClusterChoice cc = choose_cluster(o, n, dtype, num_tours, cus, pl);
     if (cc.kind == 1) {
         const CPlan& cp = cc.band;
         out12[0] = cp.g.CS; out12[1] = cp.g.CR; out12[2] = cp.g.CD; out12[3] = cp.g.nt;
@@ -815,9 +897,10 @@ extern "C" int tsp2opt_cluster_plan(int32_t n, int32_t dtype, int64_t num_tours,
 
 extern "C" int tsp2opt_plan(int32_t n, int32_t dtype, int32_t device, int32_t* out7)
 {
+    const Opts o = t_opts;
     if (n < 1 || n > TSP2OPT_MAX_N || !out7) return fail(TSP2OPT_E_ARG, "bad argument");
     if (dtype != TSP2OPT_DTYPE_F32 && dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
-    const Plan pl = make_plan(n, dtype);
+    const Plan pl = make_plan(o, n, dtype);
     out7[0] = pl.g.nt; out7[1] = pl.g.qclass; out7[2] = (int32_t)pl.lds;
     out7[3] = pl.g.NS; out7[4] = pl.g.G; out7[5] = pl.g.MS; out7[6] = 0;
     if (device >= 0) {
@@ -826,8 +909,8 @@ extern "C" int tsp2opt_plan(int32_t n, int32_t dtype, int32_t device, int32_t* o
         Params p{};
         p.g = pl.g;
         int bpc = 0;
-        const int rc = dtype == TSP2OPT_DTYPE_F64 ? dispatch_main<double>(p, pl, device, nullptr, &bpc)
-                                                  : dispatch_main<float>(p, pl, device, nullptr, &bpc);
+        const int rc = dtype == TSP2OPT_DTYPE_F64 ? dispatch_main<double>(o, p, pl, device, nullptr, &bpc)
+                                                  : dispatch_main<float>(o, p, pl, device, nullptr, &bpc);
         if (rc) return rc;
         out7[6] = bpc;
     }

@@ -103,7 +103,8 @@ __global__ void k_indep_finish(const int32_t* iters, int32_t* sweeps, const int3
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= num_tours || !sweeps) return;
     const int st = status ? status[k] : 0;
-    if (st & (TSP2OPT_ST_BAD_INDEX | TSP2OPT_ST_NOT_CLOSED | TSP2OPT_ST_NONFINITE | TSP2OPT_ST_RANGE))
+    if (st & (TSP2OPT_ST_BAD_INDEX | TSP2OPT_ST_NOT_CLOSED | TSP2OPT_ST_NONFINITE | TSP2OPT_ST_RANGE |
+              TSP2OPT_ST_INTERNAL))
         sweeps[k] = 0;
     else
         sweeps[k] = (st & (TSP2OPT_ST_CAPPED | TSP2OPT_ST_TIME)) ? iters[k] : iters[k] + 1;

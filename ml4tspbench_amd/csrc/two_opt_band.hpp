@@ -615,8 +615,14 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
 #endif
         }
         if (aborted) {
-            if (wc == 0 && tid == 0 && p.status) p.status[tk] = TSP2OPT_ST_INTERNAL;
-            return;                             // cluster broken: leave the remaining tours untouched
+            // cluster broken (a workgroup is missing): this tour and every later tour of the cluster stay
+            // untouched and are flagged, by whichever workgroups got here (same values: idempotent)
+            if (tid == 0)
+                for (int64_t t = tk; t < p.num_tours; t += p.num_clusters) {
+                    if (p.status) p.status[t] = TSP2OPT_ST_INTERNAL;
+                    p.iters[t] = 0;
+                }
+            return;
         }
         if (wc == 0) {
             for (int k = tid; k <= n; k += nt) gt[k] = (int64_t)v.tour[k];

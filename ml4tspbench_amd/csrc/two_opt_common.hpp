@@ -11,6 +11,7 @@ constexpr int kMaxCand = 64;          // exact re-evaluation list (macro steps) 
 constexpr int kMaxWaves = 16;         // 1024 threads
 constexpr int kModeIndep = 0;         // run from iteration 0 until the tour's own stop test
 constexpr int kModeForced = 1;        // continue to the group's iteration count (coupled mode)
+constexpr int kModeValidate = 2;      // stage + validate only: status written, 0 iterations (test knob: lock-step replay)
 constexpr unsigned kNoMove = 0u;      // packed (i<<16|j) == 0 <=> flat argmin index 0 <=> no move
 constexpr unsigned kFullSweep = 0xffffffffu;   // "last move" value that asks for a full filter sweep
 

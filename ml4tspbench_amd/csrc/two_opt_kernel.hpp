@@ -847,6 +847,10 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
             }
             continue;
         }
+        if (p.mode == kModeValidate) {          // (uniform branch)
+            if (tid == 0) { p.iters[tk] = 0; if (p.status) p.status[tk] = 0; }
+            continue;
+        }
         if constexpr (Q != 0) {
             const double cx = ctl->cx, cy = ctl->cy, sc = ctl->sc;
             for (int w = tid; w < 8 * Q; w += nt) {
@@ -950,8 +954,14 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
 
         // ---- write back ------------------------------------------------------------------------
         __builtin_amdgcn_s_setprio(0);
-        if (CL && st == TSP2OPT_ST_INTERNAL) {  // cluster broken (a workgroup is missing): tours untouched
-            if (g.wc == 0 && tid == 0 && p.status) p.status[tk] = st;
+        if (CL && st == TSP2OPT_ST_INTERNAL) {
+            // cluster broken (a workgroup is missing): this tour and every later tour of the cluster stay
+            // untouched and are flagged, by whichever workgroups got here (same values: idempotent)
+            if (tid == 0)
+                for (int64_t t = tk; t < p.num_tours; t += p.num_clusters) {
+                    if (p.status) p.status[t] = st;
+                    p.iters[t] = 0;
+                }
             return;
         }
         if (CL && g.wc != 0) continue;          // every workgroup holds the same tour; the first writes it

@@ -318,7 +318,25 @@ def g9(ref):   # edge cases
     case("g9_n33_indep_f64", ref, pts, tours)
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G9": g9}
+def g10(ref):  # coupled groups whose converged tours RE-ACTIVATE: with coordinates of scale 1e-4 many real
+    # moves gain less than the 1e-6 threshold, so a tour that has stopped on its own keeps applying them
+    # while its siblings run (two_opt.py:40-42) and can be active again when the slowest sibling
+    # converges -- the group then runs past the maximum of its tours' own iteration counts
+    rng = np.random.default_rng(110)
+    for n, inst, scale, dt in ((12, 6, 1.0e-5, np.float64), (50, 8, 1.0e-4, np.float64),
+                               (100, 4, 3.0e-5, np.float64), (50, 6, 1.0e-4, np.float32)):
+        pts = (uniform_points(rng, inst, n) * scale).astype(dt)
+        tours = [random_tour(rng, n) for _ in range(inst * 8)]
+        tag = "f64" if dt == np.float64 else "f32"
+        entry = "tsp_2opt" if dt == np.float64 else "batched"
+        case(f"g10_n{n}_reactivating_group8_{tag}", ref, pts, tours, tpi=8, group=8, entry=entry)
+        case(f"g10_n{n}_reactivating_as_indep_{tag}", ref, pts, tours, tpi=8, group=1, entry=entry)
+    pts = uniform_points(rng, 4, 50) * 1.0e-4
+    tours = [random_tour(rng, 50) for _ in range(32)]
+    case("g10_n50_reactivating_group8_cap40_f64", ref, pts, tours, tpi=8, group=8, max_it=40)
+
+
+ALL = {"G10": g10, "G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G9": g9}
 
 
 def main():

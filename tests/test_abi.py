@@ -51,6 +51,10 @@ def test_argument_validation_without_gpu():
     rc = L.tsp2opt_solve(ctypes.c_void_p(8), ctypes.c_void_p(8), None, None, None, None, 4, 10, 1, 1,
                          10, 0.0, 7, 0, None, 0, None)
     assert rc == -1 and b"dtype" in L.tsp2opt_last_error()
+    # the coupled call has no wall-clock limit in the reference: rejected, not silently ignored
+    rc = L.tsp2opt_solve(ctypes.c_void_p(8), ctypes.c_void_p(8), None, None, None, None, 8, 10, 4, 4,
+                         10, 0.5, 1, 0, None, 0, None)
+    assert rc == -1 and b"time_limit_s" in L.tsp2opt_last_error()
     # misaligned arrays / workspace would fault inside the kernels: rejected up front
     rc = L.tsp2opt_solve(ctypes.c_void_p(8), ctypes.c_void_p(12), None, None, None, None, 4, 10, 1, 1,
                          10, 0.0, 1, 0, None, 0, None)

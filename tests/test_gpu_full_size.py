@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 #            config      mode           cap    oracle sample (tours)
 FULL = [("tsp50", "independent", 5000, 8), ("tsp100", "independent", 5000, 8),
         ("tsp500", "independent", 5000, 4), ("tsp500", "grouped", 5000, 0),
-        ("tsp1000", "independent", 5000, 2), ("tsp10000", "independent", 60, 0)]
+        ("tsp1000", "independent", 5000, 2), ("tsp10000", "independent", 5000, 0)]
 
 
 @pytest.mark.parametrize("config,mode,cap,sample", FULL, ids=[f"{c}-{m}" for c, m, _, _ in FULL])
@@ -49,7 +49,14 @@ def test_full_size_properties(oracle, config, mode, cap, sample):
     if group > 1:
         assert (iters.reshape(-1, group) == iters.reshape(-1, group)[:, :1]).all()
     if config == "tsp10000":
-        assert capped.all()                                                     # 60 iterations do not converge
+        assert capped.all()             # BASELINE's cap: 5000 iterations do not converge a random TSP-10000 tour
+        # the oracle needs minutes per tour for 5000 sweeps of 5e7 pairs: check the first iterations
+        # of the same tours instead (bit-equal at a lowered cap; the trajectory is a prefix of the full run)
+        low, k = 20, 4
+        ref, ref_it, _ = oracle.solve(pts[:k], tours[:k], max_iterations=low, threads=8)
+        pre = amd.two_opt_device(d_pts[:k], d_tours[:k], max_iterations=low, want_lengths=False)
+        torch.cuda.synchronize()
+        assert np.array_equal(pre.tours.cpu().numpy(), ref) and np.array_equal(pre.iterations.cpu().numpy(), ref_it)
         return
     assert not capped.any()
     # fixed point: an independent second pass over the results changes nothing
@@ -65,3 +72,49 @@ def test_full_size_properties(oracle, config, mode, cap, sample):
         ref, ref_it, _ = oracle.solve(pts[: (sample + tpi - 1) // tpi], out, tours_per_instance=tpi,
                                       max_iterations=cap, threads=8)
         assert (ref_it == 0).all() and np.array_equal(ref, out)                # 2-optimal for the oracle too
+
+
+#             config     knn  oracle sample (instances)
+GREEDY = [("tsp50", 0, 4), ("tsp100", 0, 4), ("tsp500", 0, 1), ("tsp1000", 50, 1)]
+
+
+@pytest.mark.parametrize("config,knn,sample", GREEDY, ids=[c for c, _, _ in GREEDY])
+def test_full_size_greedy_start_pipeline(oracle, config, knn, sample):
+    """BASELINE.json configs 1-4 as they are named: heat map -> greedy edge-merge decode -> 2-opt, all
+    on the device at full size (synthetic heat maps, dense for configs 1-3, k = 50 sparse for config 4).
+    Properties on the whole batch, both CPU oracles on a sample of instances (bit-exact)."""
+    import ml4tspbench_amd as amd
+    from ml4tspbench_amd import _lib
+    from oracle import greedy_oracle
+    n, inst, tpi = bench.CONFIGS[config]
+    rng = np.random.default_rng(1234)
+    pts = rng.random((inst, n, 2))
+    dev = torch.device("cuda", 0)
+    d_pts = torch.from_numpy(pts).to(dev)
+    heat = bench.make_heat(d_pts, tpi, knn, 1234)
+    start = amd.greedy_decode_device(heat, d_pts, maps_per_instance=tpi)
+    ev0 = amd.evaluate_tours(d_pts, start, tours_per_instance=tpi)
+    res = amd.two_opt_device(d_pts, start, tours_per_instance=tpi, max_iterations=5000)
+    ev = amd.evaluate_tours(d_pts, res.tours, tours_per_instance=tpi)
+    torch.cuda.synchronize()
+    status = res.status.cpu().numpy()
+    assert (status & (15 | _lib.ST_INTERNAL | _lib.ST_CAPPED)).max(initial=0) == 0
+    assert ((ev0.valid.cpu().numpy() & 7) == 7).all() and ((ev.valid.cpu().numpy() & 7) == 7).all()
+    assert (ev.lengths <= ev0.lengths + 1e-9).all()
+    assert float(ev.lengths.mean()) < 0.97 * float(ev0.lengths.mean())      # 2-opt really improves greedy tours
+    best = ev.best_index.cpu().numpy()
+    lens = ev.lengths.cpu().numpy().reshape(inst, tpi)
+    assert np.array_equal(best, np.arange(inst) * tpi + lens.argmin(axis=1))
+    fix = amd.two_opt_device(d_pts, res.tours, tours_per_instance=tpi, max_iterations=5000)
+    torch.cuda.synchronize()
+    assert torch.equal(fix.tours, res.tours) and int(fix.iterations.max().item()) == 0
+    h_np = heat[:sample * tpi].cpu().numpy()
+    got_start = start[:sample * tpi].cpu().numpy()
+    got = res.tours[:sample * tpi].cpu().numpy()
+    got_it = res.iterations[:sample * tpi].cpu().numpy()
+    for k in range(sample):
+        ref_t = greedy_oracle.greedy(pts[k], h_np[k * tpi:(k + 1) * tpi])
+        assert np.array_equal(ref_t, got_start[k * tpi:(k + 1) * tpi]), k
+        ref_o, ref_it, _ = oracle.solve(pts[k:k + 1], ref_t, tours_per_instance=tpi, max_iterations=5000, threads=8)
+        assert np.array_equal(ref_o, got[k * tpi:(k + 1) * tpi]), k
+        assert np.array_equal(ref_it, got_it[k * tpi:(k + 1) * tpi]), k

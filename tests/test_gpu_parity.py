@@ -326,3 +326,137 @@ def test_gpu_every_n_matches_oracle(amd, oracle, lo, hi, step, force):
     finally:
         L.tsp2opt_debug_cluster_mode(-1)
     assert not bad, bad
+
+
+# ---- coupled mode: k_group_lockstep's active path -------------------------------------------------
+def _group_goldens():
+    return [f for f in golden_files() if load_golden(f)["group_size"] > 1]
+
+
+@pytest.mark.parametrize("path", _group_goldens(), ids=lambda p: p.split("/")[-1][:-4])
+def test_gpu_forced_lockstep_matches_reference_golden(amd, path):
+    """tsp2opt_debug_tune(6, 1): the coupled call is replayed by k_group_lockstep from iteration 0
+    (phase 1 only validates, no forced continuation), so its sweep / argmin / global-memory reversal /
+    cap handling runs on every grouped fixture -- bit-exact against the reference's outputs."""
+    from ml4tspbench_amd import _lib
+    g = load_golden(path)
+    pts = g["points"].astype(np.float64) if g["entry"] == "tsp_2opt" else g["points"]
+    _lib.lib().tsp2opt_debug_tune(6, 1)
+    try:
+        out, iters, sweeps, lengths, status = _run(amd, pts, g["tours_in"], g["tours_per_instance"],
+                                                   g["group_size"], g["max_iterations"])
+    finally:
+        _lib.lib().tsp2opt_debug_tune(6, 0)
+    assert (status & (15 | 64)).max(initial=0) == 0
+    assert np.array_equal(out, g["tours_out"]), g["name"]
+    per_call = iters[::g["group_size"]]
+    assert np.array_equal(per_call, g["iterators"]), g["name"]
+    capped = per_call >= g["max_iterations"]
+    assert np.array_equal(sweeps[::g["group_size"]], np.where(capped, per_call, per_call + 1))
+    assert np.array_equal((status & 16) != 0, np.repeat(capped, g["group_size"]))
+
+
+@pytest.mark.parametrize("n,inst,tpi,scale,dtype,cap,forced", [
+    (30, 40, 8, 1.0e-5, np.float64, 5000, 0), (64, 24, 4, 1.0e-4, np.float64, 5000, 0),
+    (100, 12, 8, 3.0e-5, np.float32, 5000, 0), (200, 6, 8, 1.0e-4, np.float64, 5000, 0),
+    (500, 2, 8, 1.0e-4, np.float64, 5000, 0), (64, 24, 4, 1.0e-4, np.float64, 37, 0),
+    (50, 8, 8, 1.0, np.float64, 5000, 1), (127, 3, 2, 1.0, np.float64, 5000, 1),
+    (200, 2, 4, 1.0, np.float32, 5000, 1), (300, 1, 4, 1.0e-4, np.float64, 5000, 1),
+    (64, 4, 4, 1.0e-4, np.float64, 21, 1)])
+def test_gpu_reactivating_groups_match_oracle(amd, oracle, n, inst, tpi, scale, dtype, cap, forced):
+    """Small coordinate scales make many real moves gain less than the 1e-6 threshold: converged tours
+    keep applying them while their siblings run and are often active again at the group's target, which
+    is exactly when k_group_lockstep takes over (natural path, forced = 0) -- and the forced replay."""
+    from ml4tspbench_amd import _lib
+    rng = np.random.default_rng(4000 + n + tpi)
+    pts, tours = _random_batch(rng, inst, tpi, n, np.float64)
+    pts = (pts * scale).astype(dtype)
+    ref_out, ref_it, ref_sw = oracle.solve(pts, tours, tours_per_instance=tpi, group_size=tpi,
+                                           max_iterations=cap, threads=8)
+    if scale < 1.0 and cap == 5000:
+        _, own_it, _ = oracle.solve(pts, tours, tours_per_instance=tpi, group_size=1, threads=8)
+        assert (ref_it.reshape(-1, tpi)[:, 0] > own_it.reshape(-1, tpi).max(axis=1)).any(), \
+            "case does not re-activate: it would not reach the lock-step kernel"
+    _lib.lib().tsp2opt_debug_tune(6, forced)
+    try:
+        out, iters, sweeps, _, status = _run(amd, pts, tours, tpi, tpi, cap)
+    finally:
+        _lib.lib().tsp2opt_debug_tune(6, 0)
+    assert (status & (15 | 64)).max(initial=0) == 0
+    assert np.array_equal(out, ref_out)
+    assert np.array_equal(iters, ref_it) and np.array_equal(sweeps, ref_sw)
+
+
+def test_gpu_forced_lockstep_reports_invalid_tours(amd):
+    from ml4tspbench_amd import _lib
+    rng = np.random.default_rng(77)
+    pts, tours = _random_batch(rng, 2, 4, 40, np.float64)
+    bad = tours.copy()
+    bad[1, 5] = 99
+    _lib.lib().tsp2opt_debug_tune(6, 1)
+    try:
+        out, iters, sweeps, _, status = _run(amd, pts, bad, 4, 4, 5000)
+    finally:
+        _lib.lib().tsp2opt_debug_tune(6, 0)
+    assert status[1] & _lib.ST_BAD_INDEX and np.array_equal(out[:4], bad[:4])     # whole group untouched
+    assert (status[4:] & 15).max() == 0 and (iters[4:] > 0).all()
+
+
+# ---- co-residency of cluster kernels ----------------------------------------------------------------
+@pytest.mark.parametrize("n,variant", [(1000, 0), (3000, 0), (1000, 1)])
+def test_gpu_two_cluster_solves_on_two_streams(amd, oracle, n, variant):
+    """Two cluster-kernel solves issued back to back on two streams: each needs all its workgroups
+    resident at once, so the library chains cluster launches of one device through an event.  Both
+    results must be bit-exact (no barrier timeout, no TSP2OPT_ST_INTERNAL)."""
+    from ml4tspbench_amd import _lib
+    cap = 400 if n <= 1000 else 40
+    rng = np.random.default_rng(31 + n)
+    dev = torch.device("cuda", 0)
+    batches = [_random_batch(rng, 3, 1, n, np.float64) for _ in range(2)]
+    refs = [oracle.solve(p, t, max_iterations=cap, threads=8) for p, t in batches]
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    _lib.lib().tsp2opt_debug_tune(3, variant)
+    try:
+        assert _lib.cluster_plan(n, _lib.DTYPE_F64, 3, cus)["workgroups_per_tour"] >= 2
+        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        d_in = [(torch.from_numpy(p).to(dev), torch.from_numpy(t).to(dev)) for p, t in batches]
+        torch.cuda.synchronize()
+        res = []
+        for rep in range(3):                         # interleaved: A B A B A B, no host synchronisation
+            for s, (dp, dt) in zip(streams, d_in):
+                with torch.cuda.stream(s):
+                    r = amd.two_opt_device(dp, dt, max_iterations=cap, want_lengths=False)
+                if rep == 2:
+                    res.append(r)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().tsp2opt_debug_tune(3, 0)
+    for r, (ref_out, ref_it, _) in zip(res, refs):
+        st = r.status.cpu().numpy()
+        assert (st & (15 | _lib.ST_INTERNAL)).max(initial=0) == 0
+        assert np.array_equal(r.tours.cpu().numpy(), ref_out)
+        assert np.array_equal(r.iterations.cpu().numpy(), ref_it)
+
+
+def test_gpu_single_workgroup_geometry_boundaries(amd, oracle):
+    """One workgroup per tour (cluster choice off) across the filter-class / thread-count switches above
+    N = 700: class 256 compiled for 512 threads, the re-plan near N = 1281..1340, class 512 beyond."""
+    from ml4tspbench_amd import _lib
+    L = _lib.lib()
+    ns = list(range(701, 1400, 37)) + [1279, 1280, 1281, 1290, 1336, 1340, 1341, 1345, 1500, 1900, 2600]
+    L.tsp2opt_debug_cluster_mode(0)
+    bad = []
+    try:
+        for n in ns:
+            for dtype in (np.float64, np.float32):
+                rng = np.random.default_rng(n * 5 + (dtype == np.float32))
+                pts, tours = _random_batch(rng, 2, 1, n, dtype)
+                cap = 120
+                ref_out, ref_it, ref_sw = oracle.solve(pts, tours, max_iterations=cap, threads=8)
+                out, iters, sweeps, _, status = _run(amd, pts, tours, 1, 1, cap, lengths=False)
+                if not (np.array_equal(out, ref_out) and np.array_equal(iters, ref_it)
+                        and np.array_equal(sweeps, ref_sw) and (status & (15 | 64)).max(initial=0) == 0):
+                    bad.append((n, dtype.__name__))
+    finally:
+        L.tsp2opt_debug_cluster_mode(-1)
+    assert not bad, bad

@@ -68,7 +68,8 @@ def test_oracle_lengths_never_increase(oracle):
 # not correctly rounded) differs from the reference with an IEEE sqrt: only inputs where two deltas
 # tie to the last bit -- regular grids, and the fp-noise moves that converged tours of a coupled
 # group keep applying.  See DESIGN.md section 2.
-NATIVE_DIFFERS = {"g9_grid8_group6_f64", "g9_grid8_indep_f64", "g3_n50_group16_f64"}
+NATIVE_DIFFERS = {"g9_grid8_group6_f64", "g9_grid8_indep_f64", "g3_n50_group16_f64",
+                  "g10_n50_reactivating_group8_f64"}
 
 
 def test_native_run_differs_only_on_tie_heavy_inputs():
@@ -80,3 +81,23 @@ def test_native_run_differs_only_on_tie_heavy_inputs():
             # even then both runs are valid 2-opt results of the same tours: same multiset per tour
             assert np.array_equal(np.sort(g["tours_out"], axis=1), np.sort(g["tours_out_native"], axis=1))
     assert differing == NATIVE_DIFFERS
+
+
+def test_reactivating_goldens_really_reactivate():
+    """The g10 group fixtures exist to reach k_group_lockstep's active path: the reference's shared
+    iterator must exceed the maximum of the same tours' own (independent) iteration counts in at least
+    one group of every uncapped fixture."""
+    import glob, os
+    from conftest import GOLDEN_DIR
+    seen = 0
+    for path in sorted(glob.glob(os.path.join(GOLDEN_DIR, "g10_*_group8_f*.npz"))):
+        g = load_golden(path)
+        if "cap" in g["name"]:
+            continue
+        ind = load_golden(path.replace("_group8_", "_as_indep_"))
+        assert np.array_equal(ind["tours_in"], g["tours_in"])
+        own_max = ind["iterators"].reshape(-1, g["group_size"]).max(axis=1)
+        assert (g["iterators"] >= own_max).all()
+        assert (g["iterators"] > own_max).any(), g["name"]
+        seen += 1
+    assert seen >= 4

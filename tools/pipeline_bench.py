@@ -37,27 +37,7 @@ CONFIGS = {            # N, instances, heat maps per instance  (BASELINE.json co
 }
 
 
-def make_heat(pts: torch.Tensor, per: int, knn: int, seed: int) -> torch.Tensor:
-    """(I,N,2) float64 -> (I*per, N, N) float32 heat maps, built in chunks on the device."""
-    inst, n, _ = pts.shape
-    g = torch.Generator(device=pts.device)
-    g.manual_seed(seed)
-    out = torch.empty((inst * per, n, n), dtype=torch.float32, device=pts.device)
-    tau = 0.35 / np.sqrt(n)
-    step = max(1, (1 << 26) // (n * n * per))
-    for a in range(0, inst, step):
-        p = pts[a:a + step]
-        d = torch.cdist(p, p)                                    # (c,N,N) float64
-        h = torch.exp(-d / tau).to(torch.float32)
-        if knn:
-            kth = d.topk(knn + 1, dim=-1, largest=False).values[..., -1:]
-            h = torch.where(d <= kth, h, torch.zeros_like(h))
-        h = h.repeat_interleave(per, dim=0)
-        noise = 0.6 + 0.8 * torch.rand(h.shape, generator=g, device=pts.device, dtype=torch.float32)
-        h = h * noise
-        h.diagonal(dim1=-2, dim2=-1).zero_()
-        out[a * per:(a + step) * per] = h
-    return out
+from bench import make_heat  # noqa: E402  (shared with tests/test_gpu_full_size.py)
 
 
 def main():
