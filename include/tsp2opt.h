@@ -95,6 +95,30 @@ int tsp2opt_solve(const void* points, int64_t* tours, int32_t* iters_out, int32_
 int64_t tsp2opt_workspace_bytes(int64_t num_tours, int32_t n, int32_t group_size);
 
 /*
+ * tsp2opt_solve_noalloc -- tsp2opt_solve for callers that cannot allocate.  No counterpart in the
+ * reference: it exists for callers that may not call hipMalloc (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid it).  Same arguments, semantics and results as tsp2opt_solve
+ * minus `workspace`/`workspace_bytes`: the scratch (control words, per-group targets, per-tour
+ * counters, the cluster barrier area) lives in a 2 MiB device array inside the library, which every GPU
+ * the library runs on holds until the process ends.  The call allocates and frees nothing (no
+ * hipMalloc/hipFree, no event or stream creation) and ignores tsp2opt_profile_enable.
+ *   - Limit: tsp2opt_workspace_bytes(num_tours, n, group_size) <= tsp2opt_noalloc_max_bytes()
+ *     (about 100 000 tours); larger batches fail with TSP2OPT_E_WORKSPACE.
+ *   - One-time set-up per device (resolving the array's device address, creating the event that
+ *     orders multi-workgroup launches) happens in tsp2opt_init(device), or on the first call on that
+ *     device if tsp2opt_init was not called; call tsp2opt_init first when the first call would sit
+ *     inside a graph capture.
+ *   - Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two streams,
+ *     two threads) race.  Issue them on one stream, or order them with events.
+ */
+int tsp2opt_solve_noalloc(const void* points, int64_t* tours, int32_t* iters_out, int32_t* sweeps_out,
+                          double* lengths_out, int32_t* status_out, int64_t num_tours, int32_t n,
+                          int32_t tours_per_instance, int32_t group_size, int32_t max_iterations,
+                          double time_limit_s, int32_t dtype, int32_t device, void* hip_stream);
+int tsp2opt_init(int32_t device);
+int64_t tsp2opt_noalloc_max_bytes(void);
+
+/*
  * tsp2opt_tour_lengths -- closed-tour length of every tour, summed in double from `dtype`
  * coordinates.  Replaces the per-edge Python loop of TSPEvaluator.evaluate
  * (utils/evaluator.py:5-13) for a whole batch; used for the final "tours + lengths" gather.

@@ -32,6 +32,9 @@ _lib = None
 SYMBOLS = (
     "tsp2opt_solve",
     "tsp2opt_workspace_bytes",
+    "tsp2opt_solve_noalloc",
+    "tsp2opt_init",
+    "tsp2opt_noalloc_max_bytes",
     "tsp2opt_tour_lengths",
     "tsp2opt_evaluate",
     "tsp2opt_greedy_decode",
@@ -71,6 +74,12 @@ def lib() -> ctypes.CDLL:
     L.tsp2opt_solve.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f64, i32, i32,
                                 vp, i64, vp]
     L.tsp2opt_solve.restype = ctypes.c_int
+    L.tsp2opt_solve_noalloc.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f64, i32, i32, vp]
+    L.tsp2opt_solve_noalloc.restype = ctypes.c_int
+    L.tsp2opt_init.argtypes = [i32]
+    L.tsp2opt_init.restype = ctypes.c_int
+    L.tsp2opt_noalloc_max_bytes.argtypes = []
+    L.tsp2opt_noalloc_max_bytes.restype = i64
     L.tsp2opt_workspace_bytes.argtypes = [i64, i32, i32]
     L.tsp2opt_workspace_bytes.restype = i64
     L.tsp2opt_tour_lengths.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp]

@@ -118,6 +118,42 @@ struct ClusterChain {
 };
 ClusterChain g_chain[kMaxDev];
 
+// Scratch of the allocation-free entry point (tsp2opt_solve_noalloc): the workspace of tsp2opt_solve
+// (control words, per-group targets, per-tour counters, cluster barrier words and slots) in a
+// file-scope device array.  `scratch` is only a host-side stand-in for the symbol: the device
+// address comes from hipGetSymbolAddress, once per device (every GPU holds its own copy), and that
+// pointer is what kernels, memsets and copies get.
+constexpr size_t kScratchBytes = 2u << 20;
+static __device__ __align__(256) __attribute__((used)) unsigned char scratch[kScratchBytes];
+struct ScratchDev {
+    std::mutex mu;
+    void* ptr = nullptr;
+};
+ScratchDev g_scratch[kMaxDev];
+
+// once per device, with that device current: resolve the device address of `scratch` and create the
+// event cluster launches are chained through (so that the entry point itself never creates anything)
+int scratch_setup(int device, void** out)
+{
+    if (device < 0 || device >= kMaxDev) return fail(TSP2OPT_E_ARG, "device ordinal beyond the supported 16");
+    ScratchDev& sd = g_scratch[device];
+    std::lock_guard<std::mutex> lk(sd.mu);
+    if (!sd.ptr) {
+        void* ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr || (reinterpret_cast<uintptr_t>(ptr) % 256))
+            return fail(TSP2OPT_E_HIP, "hipGetSymbolAddress returned an unusable address");
+        {
+            std::lock_guard<std::mutex> lc(g_chain[device].mu);
+            if (!g_chain[device].ev)
+                HIP_TRY(hipEventCreateWithFlags(&g_chain[device].ev, hipEventDisableTiming));
+        }
+        sd.ptr = ptr;
+    }
+    if (out) *out = sd.ptr;
+    return 0;
+}
+
 int chain_begin(int device, hipStream_t stream)
 {
     if (device < 0 || device >= kMaxDev) return 0;
@@ -706,6 +742,41 @@ extern "C" int tsp2opt_solve(const void* points, int64_t* tours, int32_t* iters_
         (void)hipFree(ws);
     }
     return rc;
+}
+
+extern "C" int tsp2opt_init(int32_t device)
+{
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(TSP2OPT_E_HIP, "hipSetDevice failed");
+    return scratch_setup(device, nullptr);
+}
+
+extern "C" int64_t tsp2opt_noalloc_max_bytes(void) { return (int64_t)kScratchBytes; }
+
+extern "C" int tsp2opt_solve_noalloc(const void* points, int64_t* tours, int32_t* iters_out,
+                                     int32_t* sweeps_out, double* lengths_out, int32_t* status_out,
+                                     int64_t num_tours, int32_t n, int32_t tours_per_instance,
+                                     int32_t group_size, int32_t max_iterations, double time_limit_s,
+                                     int32_t dtype, int32_t device, void* hip_stream)
+{
+    Opts o = t_opts;
+    o.profile = 0;                              // profiling creates HIP events: not on this path
+    int rc = check_solve_args(points, tours, iters_out, sweeps_out, lengths_out, status_out, num_tours, n,
+                              tours_per_instance, group_size, max_iterations, time_limit_s, dtype);
+    if (rc) return rc;
+    const size_t need = ws_layout(num_tours, group_size).total;
+    if (need > kScratchBytes)
+        return fail(TSP2OPT_E_WORKSPACE,
+                    "batch too large for tsp2opt_solve_noalloc: tsp2opt_workspace_bytes(...) exceeds "
+                    "tsp2opt_noalloc_max_bytes() (2 MiB, about 100 000 tours); use tsp2opt_solve");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(TSP2OPT_E_HIP, "hipSetDevice failed");
+    void* ws = nullptr;
+    rc = scratch_setup(device, &ws);            // first call on a device only; tsp2opt_init does it ahead
+    if (rc) return rc;
+    return solve_any(o, points, tours, iters_out, sweeps_out, lengths_out, status_out, num_tours, n,
+                     tours_per_instance, group_size, max_iterations, time_limit_s, dtype, device, ws,
+                     static_cast<hipStream_t>(hip_stream));
 }
 
 extern "C" int tsp2opt_tour_lengths(const void* points, const int64_t* tours, double* lengths_out,
