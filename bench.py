@@ -40,6 +40,34 @@ CONFIGS = {
 }
 FLOP_PER_PAIR = 15.0          # 2 x (2 sub + 2 mul + add + sqrt) + 3 add/sub
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
+PEAK_FP64_VALU_TFLOPS = 78.6   # SURVEY.md 8(d3) / BASELINE.md: the fp64 vector peak
+
+
+def lib_sha256() -> str:
+    import hashlib
+    from ml4tspbench_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
+def pmc_for_this_build(config: str, mode: str, dtype: str):
+    """Counter-derived figures of the headline kernel (rocprofv3 --pmc cannot run in-process): the
+    newest committed profiles/*_tsp500_pmc_summary.json whose `lib_sha256` is THIS library's, else None
+    -- a stale number is never quoted for a changed kernel."""
+    if not (config == "tsp500" and mode == "independent" and dtype == "f64"):
+        return None, "PMC passes exist for the default workload only"
+    import glob
+    sha = lib_sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_tsp500_pmc_summary.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                d = json.load(fh)
+        except Exception:
+            continue
+        if d.get("lib_sha256") == sha:
+            d["_file"] = os.path.relpath(path, ROOT)
+            return d, None
+    return None, f"no PMC summary under profiles/ was measured on this build (lib sha256 {sha[:12]})"
 
 
 def make_batch(name: str, seed: int, dtype):
@@ -87,6 +115,7 @@ def cpu_baseline(name: str, pts: np.ndarray, tours: np.ndarray, tpi: int, group:
     iteration cap.  Returns the baseline dict, the oracle's tours/iterations and the cap it ran with."""
     from oracle import two_opt_oracle as orc
     n = pts.shape[1]
+    # 16 = the CPU share of a one-GPU box in this pool (its os.cpu_count() shows the whole machine)
     threads = max(1, min(16, os.cpu_count() or 1, orc.max_threads()))
     pairs = (n - 1) * (n - 2) // 2
     budget = 20.0 * 3.0e8 * threads                  # ~3e8 pair evaluations per core-second
@@ -109,6 +138,7 @@ def cpu_baseline(name: str, pts: np.ndarray, tours: np.ndarray, tpi: int, group:
         "value": float(sweeps.astype(np.int64).sum()) * pairs / dt,
         "unit": "pair-deltas/s",
         "cores": threads,
+        "cores_total": os.cpu_count(),
         "kind": "port",
         "sample": f"first {want} of {len(tours)} tours of the same batch{capnote}, {dt:.1f} s, "
                   f"{want / dt:.2f} tours/s, OpenMP over tours",
@@ -175,6 +205,9 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--max-iterations", type=int, default=5000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank solves its own batch; strong: ONE batch (BASELINE.json configs[2]: "
+                         "128 instances x 16 tours) sharded over the ranks by sharding.solve_sharded")
     ap.add_argument("--instances", type=int, default=0, help="diagnostic: override the number of instances")
     ap.add_argument("--tune", action="append", default=[], help="diagnostic: tsp2opt_debug_tune what=value")
     ap.add_argument("--cluster-mode", type=int, default=-1,
@@ -214,7 +247,9 @@ def main():
     if args.instances > 0:
         CONFIGS[args.config] = (CONFIGS[args.config][0], args.instances, CONFIGS[args.config][2])
     n, inst, tpi = CONFIGS[args.config]
-    pts, tours, tpi = make_batch(args.config, 1234 + rank, np_dtype)   # seed 1234 (utils/args.py:27)
+    strong = args.scaling == "strong"
+    # seed 1234 (utils/args.py:27); strong scaling: every rank holds the same batch
+    pts, tours, tpi = make_batch(args.config, 1234 + (0 if strong else rank), np_dtype)
     group = tpi if args.mode == "grouped" and tpi > 1 else 1
     T = len(tours)
     pairs = (n - 1) * (n - 2) // 2
@@ -226,7 +261,15 @@ def main():
         gather_t = torch.empty((world * T, pack_tours(d_tours[:1]).shape[1]), dtype=torch.uint8, device=dev)
         gather_l = torch.empty(world * T, dtype=torch.float64, device=dev)
 
+    def step_strong():
+        # the tested function is the timed one: contiguous instance blocks per rank, one final all_gather
+        from ml4tspbench_amd.sharding import solve_sharded
+        return solve_sharded(d_pts, d_tours, tours_per_instance=tpi, group_size=group,
+                             max_iterations=args.max_iterations, want_result=True)
+
     def step():
+        if strong:
+            return step_strong()
         res = amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi, group_size=group,
                                  max_iterations=args.max_iterations, want_lengths=True)
         if use_dist:        # the only exchange of the path: final gather of tours (as int16) and lengths
@@ -260,12 +303,20 @@ def main():
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
         dt = float(tdt.item())
 
-    if use_dist:            # the gathered copy holds this rank's tours at its own offset
-        assert torch.equal(res.all_tours[rank * T:(rank + 1) * T], res.tours), "final gather corrupted the tours"
+    if strong:
+        whole = res                                  # ShardedResult: whole batch on every rank
+        res = whole.local                            # this rank's block (TwoOptResult)
+        b0, b1 = whole.block
+        assert whole.tours.shape[0] == T and torch.equal(whole.tours[b0:b1], res.tours), "final gather corrupted the tours"
+        local_T = b1 - b0
+    else:
+        local_T = T
+        if use_dist:        # the gathered copy holds this rank's tours at its own offset
+            assert torch.equal(res.all_tours[rank * T:(rank + 1) * T], res.tours), "final gather corrupted the tours"
     sweeps = res.sweeps.to(torch.int64)
     iters = res.iterations
-    my_pd = torch.tensor([float(sweeps.sum().item()) * pairs, float(T), float(iters.sum().item()),
-                          float(iters.max().item())], dtype=torch.float64, device=dev)
+    my_pd = torch.tensor([float(sweeps.sum().item()) * pairs, float(local_T), float(iters.sum().item()),
+                          float(iters.max().item()) if local_T else 0.0], dtype=torch.float64, device=dev)
     if use_dist:
         mx = my_pd[3:].clone()
         dist.all_reduce(my_pd, op=dist.ReduceOp.SUM)
@@ -274,10 +325,10 @@ def main():
     pd_per_step, tours_total, it_sum, it_max = [float(x) for x in my_pd.tolist()]
     value = pd_per_step * args.steps / dt
     status = res.status.cpu().numpy()
-    assert (status & 15).max(initial=0) == 0, "input rejected"
+    assert (status & (15 | 64)).max(initial=0) == 0, "input rejected"
 
     gap = None
-    if args.dtype == "f32" and rank == 0:
+    if args.dtype == "f32" and rank == 0 and not strong:
         # north_star: "the fp32 path must give tour lengths within 1e-6 relative, with the optimality
         # gap reported": the same start tours solved in fp64 (untimed), both lengths summed in double
         r64 = amd.two_opt_device(d_pts.double(), d_tours, tours_per_instance=tpi, group_size=group,
@@ -294,30 +345,48 @@ def main():
         forced_ms = float(np.mean([k[1] for k in kern_ms])) if kern_ms else None
         my_pairs = float(sweeps.sum().item()) * pairs
         roof = None
-        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes of this
-        try:                    # same command (tools/pmc_passes.sh); counters cannot be read in-process
-            if args.config == "tsp500" and args.mode == "independent" and args.dtype == "f64":
-                with open(os.path.join(ROOT, "profiles", "r01_tsp500_pmc_summary.json")) as fh:
-                    traffic = [v for k, v in json.load(fh)["derived"].items() if k.startswith("hbm_bytes")][0]
-        except Exception:
-            traffic = None
         if main_ms:
             kernel_ms = main_ms + (forced_ms or 0.0)
             ach = my_pairs * FLOP_PER_PAIR / (kernel_ms * 1e-3) / 1e12
+            # counter-derived figures: only for the library they were measured on (else null)
+            pmc, why = pmc_for_this_build(args.config, args.mode, args.dtype) if world == 1 else (None, "N = 1 only")
+            exe = busy = bank = evald = traffic = None
+            if pmc:
+                dv = pmc["derived"]
+                pick = lambda pre: next((v for k, v in dv.items() if k.startswith(pre)), None)
+                exe_flop, busy, bank = pick("fp32_flop_executed"), pick("valu_busy_frac"), pick("lds_bank_conflict_rate")
+                traffic, sq = pick("hbm_bytes"), pick("sqrt_lanes")
+                exe = exe_flop / (kernel_ms * 1e-3) / 1e12 if exe_flop else None
+                evald = sq / my_pairs if sq and my_pairs else None
             roof = {"bound": "valu", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
+                    "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS,
+                    "frac_fp32_peak": ach / PEAK_FP32_VALU_TFLOPS, "frac_fp64_peak": ach / PEAK_FP64_VALU_TFLOPS,
+                    "executed_tflops": exe, "executed_frac": exe / PEAK_FP32_VALU_TFLOPS if exe else None,
+                    "valu_busy": busy, "lds_bank_conflict_rate": bank, "pairs_evaluated_frac": evald,
+                    "traffic": traffic, "pmc_source": pmc["_file"] if pmc else why,
                     "kernel": "k_two_opt", "kernel_ms": kernel_ms,
-                    "note": "algorithmic 15 FLOP per pair-delta / HIP-event duration of the persistent "
-                            "kernel (rank 0); VALU-bound, HBM traffic is O(N) per tour"}
+                    "note": "achieved/frac are REFERENCE-EQUIVALENT work, not executed FLOP: the reference "
+                            "algorithm's pair-deltas (sweeps x (N-1)(N-2)/2) x 15 FLOP / HIP-event duration of the "
+                            "persistent kernel (rank 0), priced against the FP32 vector peak 157.3 TFLOP/s because "
+                            "the kernel computes in fp32 (exact fp64 only for near-ties) although results are "
+                            "bit-exact fp64 (dtype); against the fp64 vector peak 78.6 the same figure is "
+                            "frac_fp64_peak and may exceed 1.  The kernel re-evaluates only pairs_evaluated_frac of the "
+                            "pairs per sweep (tile-minimum cache) at one distance per pair: executed_* and valu_busy "
+                            "are what the VALUs really did (rocprofv3 PMC passes of this build; a packed "
+                            "instruction counts once, so executed_tflops is a lower bound).  HBM traffic is O(N) per tour."}
+        if strong:
+            work = (f"TSP-{n} uniform, ONE batch of {inst} instances x {tpi} random start tours sharded over "
+                    f"{world} GPU(s) by sharding.solve_sharded (contiguous instance blocks)")
+        else:
+            work = f"TSP-{n} uniform, {inst} instances x {tpi} random start tours per GPU"
         out = {
             "metric": "2-opt pair-deltas/sec", "value": value, "unit": "pair-deltas/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"TSP-{n} uniform, {inst} instances x {tpi} random start tours "
-                                   f"per GPU, 2-opt to local optimum, max_iterations "
+            "config": {"workload": f"{work}, 2-opt to local optimum, max_iterations "
                                    f"{args.max_iterations}, {args.mode} termination",
-                       "tours_per_gpu": T, "nodes": n, "mode": args.mode,
+                       "tours_per_gpu": local_T if strong else T, "nodes": n, "mode": args.mode,
                        "parallelism": f"tours sharded over {world} GPU(s), final all_gather only"},
             "tours_per_s": tours_total * args.steps / dt,
             "mean_iterations": it_sum / tours_total, "max_iterations_seen": it_max,

@@ -12,10 +12,21 @@ BASELINE.json's north_star asks for.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Tuple
+from dataclasses import dataclass
+from typing import Any, Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+@dataclass
+class ShardedResult:
+    """solve_sharded(..., want_result=True): the whole batch on every rank + this rank's own block."""
+    tours: torch.Tensor         # (T, N+1) int64, whole batch
+    iterations: torch.Tensor    # (T,) int32, whole batch
+    lengths: torch.Tensor       # (T,) float64, whole batch
+    local: Any                  # the solver's result for this rank's block (TwoOptResult)
+    block: Tuple[int, int]      # [first, last) tour of this rank's block
 
 
 def partition(num_units: int, world: int) -> List[Tuple[int, int]]:
@@ -34,14 +45,15 @@ def partition(num_units: int, world: int) -> List[Tuple[int, int]]:
 
 def solve_sharded(points: torch.Tensor, tours: torch.Tensor, *, tours_per_instance: int = 1,
                   group_size: int = 1, max_iterations: int = 5000,
-                  solver: Optional[Callable] = None, process_group=None):
+                  solver: Optional[Callable] = None, process_group=None, want_result: bool = False):
     """Solve a batch that every rank holds, each rank doing its block of instances.
 
     points (I, N, 2), tours (I * tours_per_instance, N+1) -- identical on every rank and on the
     rank's own device.  ``solver(points, tours, tours_per_instance=, group_size=,
     max_iterations=)`` must return an object with ``tours``, ``iterations``, ``lengths`` tensors
     (default: ``two_opt_device``).  Returns ``(tours (T, N+1) int64, iterations (T,) int32,
-    lengths (T,) float64)`` for the WHOLE batch on every rank.
+    lengths (T,) float64)`` for the WHOLE batch on every rank (``want_result=True``: a
+    ``ShardedResult`` that also carries this rank's own solver result).
     """
     if solver is None:
         from .two_opt import two_opt_device
@@ -59,7 +71,10 @@ def solve_sharded(points: torch.Tensor, tours: torch.Tensor, *, tours_per_instan
     res = solver(points[i0:i1], tours[i0 * tours_per_instance:i1 * tours_per_instance],
                  tours_per_instance=tours_per_instance, group_size=group_size,
                  max_iterations=max_iterations)
+    blk = (i0 * tours_per_instance, i1 * tours_per_instance)
     if world == 1:
+        if want_result:
+            return ShardedResult(res.tours, res.iterations, res.lengths, res, blk)
         return res.tours, res.iterations, res.lengths
     # one padded all_gather per output (blocks differ by at most one instance)
     cap = max(b - a for a, b in blocks) * tours_per_instance
@@ -74,8 +89,11 @@ def solve_sharded(points: torch.Tensor, tours: torch.Tensor, *, tours_per_instan
                  for r, (a, b) in enumerate(blocks)]
         return torch.cat(parts, dim=0)
 
-    return (gather_tours(res.tours.to(dev), gather), gather(res.iterations.to(dev)),
-            gather(res.lengths.to(dev)))
+    out = (gather_tours(res.tours.to(dev), gather), gather(res.iterations.to(dev)),
+           gather(res.lengths.to(dev)))
+    if want_result:
+        return ShardedResult(out[0], out[1], out[2], res, blk)
+    return out
 
 
 def pack_tours(tours: torch.Tensor) -> torch.Tensor:

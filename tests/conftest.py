@@ -22,9 +22,14 @@ def pytest_configure(config):
 
 
 def golden_files():
-    """2-opt fixtures (oracle/gen_golden.py); the greedy decoder's are greedy_*.npz (tests/test_greedy.py)."""
-    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not os.path.basename(f).startswith("greedy_"))
+    """2-opt fixtures g<k>_*.npz (oracle/gen_golden.py); the greedy decoder's are greedy_*.npz
+    (tests/test_greedy.py), the evaluator's eval_*.npz."""
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "g[0-9]*.npz")))
+
+
+def eval_golden_files():
+    """Evaluation fixtures (oracle/gen_golden_eval.py): costs from the reference's TSPEvaluator."""
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "eval_*.npz")))
 
 
 def load_golden(path):

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_DIR, load_golden
+from conftest import GOLDEN_DIR, eval_golden_files, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -106,3 +106,41 @@ def test_evaluate_tours_flags_lengths_best(oracle):
     L = np.where(np.isnan(lengths), np.inf, lengths).reshape(inst, tpi)
     assert np.array_equal(best, np.arange(inst) * tpi + L.argmin(1))
     np.testing.assert_array_equal(ev.best_length.cpu().numpy(), L.min(1))
+
+
+@pytest.mark.parametrize("path", eval_golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_evaluate_matches_reference_evaluator(path):
+    """tsp2opt_evaluate against fixtures whose costs come from the reference's TSPEvaluator
+    (utils/evaluator.py:5-13, run by oracle/gen_golden_eval.py) and whose validity verdicts restate
+    base.py:31-32,67-72.  Flags and best index exact; lengths rtol 1e-12 (a double sum in another order;
+    fp32 fixture: the reference accumulates float32 distances, 1e-5)."""
+    from ml4tspbench_amd import evaluate_tours
+    z = np.load(path)
+    tpi = int(z["tours_per_instance"])
+    dev = torch.device("cuda", 0)
+    ev = evaluate_tours(torch.from_numpy(z["points"]).to(dev), torch.from_numpy(z["tours"]).to(dev),
+                        tours_per_instance=tpi)
+    torch.cuda.synchronize()
+    valid = ev.valid.cpu().numpy()
+    assert np.array_equal((valid & 1) == 1, z["is_permutation"])
+    assert np.array_equal((valid & 2) == 2, z["ends_at_zero"])
+    f32 = z["points"].dtype == np.float32
+    np.testing.assert_allclose(ev.lengths.cpu().numpy(), z["costs"], rtol=1e-5 if f32 else 1e-12)
+    np.testing.assert_allclose(ev.best_length.cpu().numpy(), z["best_cost"], rtol=1e-5 if f32 else 1e-12)
+    if not f32:
+        assert np.array_equal(ev.best_index.cpu().numpy(), z["best_index"])
+
+
+def test_plugin_validity_rule_on_reference_fixtures():
+    """The plugin's ValueError fires exactly on the tours the reference's rule rejects."""
+    from ml4tspbench_amd import ML4TSPNARLocalSearch
+    z = np.load(eval_golden_files()[0])
+    ls = ML4TSPNARLocalSearch()
+    ls.nodes_num = z["points"].shape[1]
+    for t, perm, e0 in zip(z["tours"], z["is_permutation"], z["ends_at_zero"]):
+        assert ls.is_valid_tour(t) == bool(perm)
+        if perm and e0:
+            ls._validate(t[None])
+        else:
+            with pytest.raises(ValueError, match="is not valid"):
+                ls._validate(t[None])
