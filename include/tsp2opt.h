@@ -202,6 +202,8 @@ int tsp2opt_profile_history_ms(int32_t device, int32_t calls_back, double* main_
  * accumulates shader-clock cycles per phase into workspace bytes [64,104) as five uint64:
  * filter sweep, argmin selection (reductions + exact re-evaluation), reversal, staging, whole tour
  * (thread 0 of each workgroup, summed over tours).  Never quote run times of such a launch.
+ * Only the diagnostic build of the library (python -m ml4tspbench_amd.build --fine) carries the timers;
+ * in the shipped library the call is accepted and has no effect.
  */
 int tsp2opt_debug_phase_cycles(int32_t on);
 /* Diagnostic: sweeps > 0 makes tsp2opt_solve run only that many filter sweeps per tour (hot loop in

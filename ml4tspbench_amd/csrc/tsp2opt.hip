@@ -96,7 +96,8 @@ struct Opts {
     int lcap16 = 13;            // changed-group list capacity of the band cluster kernel, in 1/16 of the groups
     int lcap16s = 13;           // changed-tile list capacity of the one-workgroup / full-window kernel, in 1/16 of the tiles
     int lds_pad = 0;            // unused LDS bytes added to the one-workgroup kernel's request (occupancy sweeps)
-    int inc_min_tiles = 2;      // tile cache only when a lane owns at least this many tiles (measured: TSP-50 / TSP-100)
+    int inc_min_tiles = 3;      // tile cache only when a lane owns at least this many tiles (measured: with one or
+                                // two tiles per lane, N <~ 110, plain full sweeps are faster than keeping the cache)
     int cluster_inc = 1;        // 0: band cluster kernel without the group-minimum cache
     int cluster_mode = -1;      // -1 auto, 0 never, >= 2 force that many workgroups per tour (tests)
     int cluster_variant = 0;    // 0 auto, 1 band kernel only (k_two_opt_cluster), 2 full-window kernel only
@@ -195,7 +196,7 @@ struct Plan {
 };
 
 constexpr size_t kLdsMax = 160 * 1024;
-constexpr size_t kCsyncBytes = 64 * 1024;   // cluster barrier words + slots (<= 256 workgroups)
+constexpr size_t kCsyncBytes = 256 * 1024;  // cluster barrier words + slots (<= 1024 clusters of <= 6 workgroups)
 const int kQClasses[] = {16, 32, 64, 128, 256, 512};
 
 
@@ -267,7 +268,7 @@ Plan make_plan_nt(const Opts& o, int n, int dtype, int cs, int nt_cap)
                 // on TSP-100/500/1000, beyond that a plain sweep is cheaper than recomputing tile by tile)
                 const size_t tiles = (size_t)GPl * NS * (MS / 2);
                 const size_t lcap = tiles * (size_t)o.lcap16s / 16 + 1;
-                const size_t need = align16(4 * tiles) + align16(2 * lcap);
+                const size_t need = align16(4 * tiles) + align16(2 * lcap) + align16(4 * (size_t)GPl * NS);
                 if (MS / 2 >= o.inc_min_tiles && (size_t)NS * (MS / 2) <= 255 && GPl <= 255 && MS / 2 <= 32 && GPl * NS <= nt &&
                     base + (size_t)g.qclass * 192 + need <= kLdsMax) {
                     g.inc = 1;
@@ -323,7 +324,8 @@ int launch_fw(Params p, const Plan& pl, int cus, int device, hipStream_t stream)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, pl.g.nt, pl.lds));
     if (per_cu < 1) return fail(TSP2OPT_E_UNSUPPORTED, "internal: cluster workgroup does not fit a CU");
     const int CS = pl.g.CS;
-    int clusters = cus / CS;
+    // every workgroup of the grid must be resident at once: at most per_cu workgroups per CU
+    int clusters = (int)std::min<int64_t>((int64_t)cus * per_cu / CS, 1024);
     if (clusters > p.num_tours) clusters = (int)p.num_tours;
     if (clusters < 1) return fail(TSP2OPT_E_UNSUPPORTED, "cluster does not fit the device");
     p.num_clusters = clusters;
@@ -511,7 +513,7 @@ ClusterChoice choose_cluster(const Opts& o, int n, int dtype, int64_t num_tours,
     // full-window cluster: needs the fast path (and one of the instantiated filter classes) with the
     // whole window in LDS; at least 4 lane groups per workgroup
     if (o.cluster_variant != 1 && cap >= 2 && pl.g.qclass != 0 && (forced || n >= 700)) {
-        const int cs = std::min(cap, std::max(1, pl.g.GP / 4));
+        const int cs = std::min(std::min(cap, 64), std::max(1, pl.g.GP / 4));    // <= 64: cluster_exchange_w
         if (cs >= 2) {
             const Plan fw = make_plan(o, n, dtype, cs);
             if (fw.g.qclass >= 128) { c.kind = 2; c.fw = fw; return c; }

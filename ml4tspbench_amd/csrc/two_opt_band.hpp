@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
         const long long t_start = p.time_limit_ticks ? wall_clock64() : 0;
         int it = 0, sweeps = 0, st = 0;
         bool aborted = false;
-        Prof pf{p.stamps != nullptr, 0, 0, 0};
+        Prof pf = make_prof(p.stamps);
         unsigned long long t_x = 0, t_tour = pf.on ? clock64() : 0;
         unsigned last = kFullSweep;             // reversal applied since the previous sweep
         for (;;) {

@@ -55,15 +55,34 @@ struct Params {
     Geo g;
 };
 
-struct Prof {                         // per-thread phase timers, only live when Params::stamps != null
-    bool on;
-    unsigned long long sweep, select, apply;
+// Phase timers (tsp2opt_debug_phase_cycles).  Only the diagnostic build (-DTSP2OPT_FINE,
+// libtsp2opt_hip_fine.so) has them: in the shipped library `on` is a compile-time false, so the timers
+// and every `if (pf.on)` vanish -- the persistent kernel sits at its VGPR limit and a dozen loop-carried
+// counters are exactly what gets spilled to scratch.
+struct Prof {
+#ifdef TSP2OPT_FINE
+    bool on = false;
+#else
+    static constexpr bool on = false;
+#endif
+    unsigned long long sweep = 0, select = 0, apply = 0;
     unsigned amb = 0, cands = 0;
     unsigned long long candcyc = 0;
 #ifdef TSP2OPT_FINE
     unsigned long long tl = 0, fine[16] = {};
 #endif
 };
+
+__device__ __forceinline__ Prof make_prof(const unsigned long long* stamps)
+{
+    Prof pf;
+#ifdef TSP2OPT_FINE
+    pf.on = stamps != nullptr;
+#else
+    (void)stamps;
+#endif
+    return pf;
+}
 
 // Diagnostic build only (-DTSP2OPT_FINE, libtsp2opt_hip_fine.so): FINE(pf, k) charges the shader-clock
 // cycles since the previous mark to slot k; the slots are summed into workspace stamps [8, 24).
@@ -137,8 +156,9 @@ struct View {
     v2f* Xq;               // x
     v2f* Yq;               // y
     v2f* Eq;               // edge lengths e[w] = |P[w] P[w+1]|
-    float* Mc;             // filter minimum of every tile (8 rows x 8 diagonals), or null
+    unsigned* Mc;          // filter minimum of every tile (8 rows x 8 diagonals) as an ordered key, or null
     uint16_t* list;        // ids of the tiles the last reversal touched
+    unsigned* Mu;          // per unit (lane): order-preserving key of the minimum over its tiles, or null
     const T* X;            // exact coordinates, node order (LDS copy or global)
 };
 

@@ -181,84 +181,174 @@ __device__ __forceinline__ Unit lane_unit(const Geo& g, int tid)
     return un;
 }
 
-// Filter sweep of one iteration.  `last` = the reversal applied since the previous sweep (packed
-// (i, j)) or kFullSweep.  With the tile cache, only tiles that read a changed window position
-// (coordinates i+1..j, edges i..j, any cyclic copy) are recomputed: every lane marks its own
-// touched tiles in closed form, the ids are compacted into a list (ballot per row block, one LDS
-// atomic per wave), the list is processed evenly by all lanes, then every lane reduces its own
-// cached tile minima exactly as the full sweep would.
+// Filter sweep of one iteration for geometries WITHOUT the tile cache: every lane walks its whole unit.
 template <int Q, bool CL, typename T>
 __device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid,
-                                      unsigned last, float& a1, float& a2, unsigned& chunk, Prof& pf)
+                                      float& a1, float& a2, unsigned& chunk, Prof& pf)
 {
-    Ctl* ctl = v.ctl;
-    const Unit un = lane_unit<CL>(g, tid);
-    bool full = !g.inc || last == kFullSweep;
     FINE_START(pf);
-    if (!full) {
-        const int MS2 = g.MS >> 1;
-        const int i = (int)(last >> 16), j = (int)(last & 0xffffu);
-        unsigned mask = 0u;                                 // touched tiles of the lane's unit (MS2 <= 32)
-        if (un.gp >= 0) {
-            for (int lo = i, hi = j; lo < g.W; lo += g.n, hi += g.n) {
-                mask |= bit_range32((lo >> 3) - un.rq0, (hi >> 3) - un.rq0, MS2);                              // rows
-                mask |= bit_range32(((lo - 9) >> 3) - un.gp - un.rq0, ((hi - 2) >> 3) - un.gp - un.rq0, MS2);  // columns
-            }
-        }
-        // compaction: prefix sum of the lanes' counts -> one atomic per wave -> every lane writes its run
-        const unsigned cnt = (unsigned)__popc(mask);
-        const unsigned incl = wave_scan_add(cnt);
-        const unsigned wtotal = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-        if (wtotal) {
-            unsigned base = 0;
-            if ((tid & 63) == 0) base = atomicAdd(&ctl->nlist, wtotal);
-            unsigned pos = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + incl - cnt;
-            const unsigned id0 = ((unsigned)un.rq0 << 8) | (unsigned)un.gpl;
-            while (mask) {
-                const unsigned b = (unsigned)__builtin_ctz(mask);
-                mask &= mask - 1u;
-                if (pos < (unsigned)g.lcap) v.list[pos] = (uint16_t)(id0 + (b << 8));
-                ++pos;
-            }
-        }
-        FINE(pf, 0);                                        // marking + compaction
-        __syncthreads();
-        const unsigned nl = ctl->nlist;
-        if (nl > (unsigned)g.lcap) {
-            full = true;                                    // most of the tour moved: plain sweep
-        } else {
-            __builtin_amdgcn_s_setprio(0);
-            for (unsigned t = (unsigned)tid; t < nl; t += (unsigned)g.nt) {
-                const unsigned id = v.list[t];
-                const int rq = (int)(id >> 8), gpl = (int)(id & 255u);
-                v.Mc[rq * g.GPl + gpl] = tile_min<Q>(v.Xq, v.Yq, v.Eq, rq, g.wc + g.CS * gpl);
-            }
-            __builtin_amdgcn_s_setprio(3);
-        }
-        FINE(pf, 1);                                        // barrier + changed tiles
-        __syncthreads();
-        if (tid == 0) ctl->nlist = 0;
-        if (!full) {
-            a1 = INFINITY;
-            a2 = INFINITY;
-            chunk = 0;
-            if (un.gp >= 0) {
-                unsigned id = ((unsigned)un.rq0 << 8) | (unsigned)un.gpl;
-                const float* mc = v.Mc + un.rq0 * g.GPl + un.gpl;
-                for (int m2 = 0; m2 < MS2; ++m2) {
-                    track(*mc, id, a1, a2, chunk);
-                    id += 256u;
-                    mc += g.GPl;
-                }
-            }
-            FINE(pf, 2);                                    // barrier + reduction of the cached minima
-            return;
-        }
-    }
     __builtin_amdgcn_s_setprio(0);
-    filter_sweep<Q, CL>(v.Xq, v.Yq, v.Eq, g.inc ? v.Mc : nullptr, g, tid, a1, a2, chunk);
+    filter_sweep<Q, CL>(v.Xq, v.Yq, v.Eq, nullptr, g, tid, a1, a2, chunk);
     __builtin_amdgcn_s_setprio(3);
     FINE(pf, 3);                                            // full sweep
+}
+
+// ------------------------------------------------------------------------------------------
+// cached path (g.inc): tile minima Mc + per-unit minima Mu, three barriers per iteration
+// ------------------------------------------------------------------------------------------
+// One iteration with the tile cache is three phases, each closed by ONE workgroup barrier:
+//   A  apply the chosen reversal to the LDS copies AND mark the tiles it touches (closed form per
+//      lane): the lane resets its unit's minimum Mu[u] to the minimum of its UNTOUCHED tiles and the
+//      touched tile ids are compacted into a list;
+//   B  the listed tiles are recomputed evenly by all lanes (or, on list overflow, every lane re-walks
+//      its whole unit): Mc[tile] = value, Mu[unit] = min(Mu[unit], value) with an LDS atomic;
+//   C  EVERY WAVE, redundantly and without talking to the others: scan Mu for the workgroup minimum m,
+//      list the units and then the tiles inside the window m + 2 eps, re-evaluate those tiles pair by
+//      pair in fp32 and decide (unique far-enough pair: certain move / window above the threshold:
+//      converged / else the exact stage, cooperatively).  All waves read the same LDS words and run
+//      the same deterministic instructions, so they reach the same decision with no exchange.
+// Mu holds order-preserving unsigned keys of the float minima so that ds_min_u32 can merge them.
+__device__ __forceinline__ unsigned fkey(float f)
+{
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float funkey(unsigned k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned umin_step(unsigned v)
+{
+    const unsigned o = (unsigned)dpp_i<CTRL, ROW_MASK>((int)v);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    v = umin_step<0xB1, 0xf>(v);
+    v = umin_step<0x4E, 0xf>(v);
+    v = umin_step<0x141, 0xf>(v);
+    v = umin_step<0x140, 0xf>(v);
+    v = umin_step<0x142, 0xa>(v);
+    v = umin_step<0x143, 0xc>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// full sweep of the lane's own unit: every tile minimum to Mc, the unit minimum to Mu
+template <int Q, bool CL, typename T>
+__device__ __forceinline__ void filter_sweep_cached(const View<T>& v, const Geo& g, int tid)
+{
+    const Unit un = lane_unit<CL>(g, tid);
+    if (un.gp < 0) return;
+    const int MS2 = g.MS >> 1;
+    int rq = un.rq0;
+    int cb = rq + un.gp;
+    v2f CX0[4], CY0[4], CX1[4], CY1[4], E0[4], E1[4], Dc[4];
+    load_block<Q, 0>(v.Xq, v.Yq, v.Eq, cb, CX0, CY0, E0);
+    const float ax = v.Xq[rq].x, ay = v.Yq[rq].x;           // P[r0]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Dc[q] = dist32x2(ax, ay, CX0[q], CY0[q]);
+    unsigned* mc = v.Mc + rq * g.GPl + un.gpl;
+    float um = INFINITY;
+    for (int m2 = 0; m2 < MS2; ++m2) {
+        float mm = macro_step<Q, 0>(v.Xq, v.Yq, v.Eq, rq, cb, CX0, CY0, CX1, CY1, E0, E1, Dc);
+        mm = __builtin_fminf(mm, macro_step<Q, 1>(v.Xq, v.Yq, v.Eq, rq, cb, CX1, CY1, CX0, CY0, E1, E0, Dc));
+        *mc = fkey(mm);
+        mc += g.GPl;
+        um = __builtin_fminf(um, mm);
+        ++rq; ++cb;
+    }
+    v.Mu[tid] = fkey(um);
+}
+
+// phase A, second half: mark the tiles reversal `mv` touches (coordinates i+1..j, edges i..j, any
+// cyclic copy), reset the unit minimum to its untouched tiles, queue the touched tile ids
+template <bool CL, typename T>
+__device__ __forceinline__ void mark_touched(const View<T>& v, const Geo& g, int tid, unsigned mv)
+{
+    const Unit un = lane_unit<CL>(g, tid);
+    const int MS2 = g.MS >> 1;
+    const int i = (int)(mv >> 16), j = (int)(mv & 0xffffu);
+    unsigned mask = 0u;                                 // touched tiles of the lane's unit (MS2 <= 32)
+    if (un.gp >= 0) {
+        for (int lo = i, hi = j; lo < g.W; lo += g.n, hi += g.n) {
+            mask |= bit_range32((lo >> 3) - un.rq0, (hi >> 3) - un.rq0, MS2);                              // rows
+            mask |= bit_range32(((lo - 9) >> 3) - un.gp - un.rq0, ((hi - 2) >> 3) - un.gp - un.rq0, MS2);  // columns
+        }
+    }
+    if (mask) {
+        // minimum of the unit's UNTOUCHED tiles; eight cached minima per LDS round trip (a plain loop
+        // would wait for every single read)
+        const unsigned* mc = v.Mc + un.rq0 * g.GPl + un.gpl;
+        const unsigned skip = MS2 >= 32 ? mask : (mask | (~0u << MS2));     // touched, or beyond the unit
+        unsigned km = 0xffffffffu;
+        for (int m0 = 0; m0 < MS2; m0 += 8) {
+            unsigned c[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int m2 = m0 + k < MS2 ? m0 + k : MS2 - 1;             // always a valid address
+                c[k] = mc[m2 * g.GPl];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) km = ((skip >> (m0 + k)) & 1u) ? km : (c[k] < km ? c[k] : km);
+        }
+        v.Mu[tid] = km;
+    }
+    // compaction: prefix sum of the lanes' counts -> one atomic per wave -> every lane writes its run
+    const unsigned cnt = (unsigned)__popc(mask);
+    const unsigned incl = wave_scan_add(cnt);
+    const unsigned wtotal = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    if (wtotal) {
+        unsigned base = 0;
+        if ((tid & 63) == 0) base = atomicAdd(&v.ctl->nlist, wtotal);
+        unsigned pos = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + incl - cnt;
+        const unsigned id0 = ((unsigned)un.rq0 << 8) | (unsigned)un.gpl;
+        while (mask) {
+            const unsigned b = (unsigned)__builtin_ctz(mask);
+            mask &= mask - 1u;
+            if (pos < (unsigned)g.lcap) v.list[pos] = (uint16_t)(id0 + (b << 8));
+            ++pos;
+        }
+    }
+}
+
+// phase B: bring Mc / Mu up to date after reversal `last` (kFullSweep: everything)
+template <int Q, bool CL, typename T>
+__device__ __forceinline__ void refresh_cached(const View<T>& v, const Geo& g, int tid, unsigned last, Prof& pf)
+{
+    Ctl* ctl = v.ctl;
+    FINE_START(pf);
+    const unsigned nl = ctl->nlist;
+    __builtin_amdgcn_s_setprio(0);
+    if (last == kFullSweep || nl > (unsigned)g.lcap) {      // (uniform) first sweep, or most of the tour moved
+        filter_sweep_cached<Q, CL>(v, g, tid);
+        FINE(pf, 3);
+    } else {
+        const float inv_ms2 = 1.0f / (float)(g.MS >> 1);
+        unsigned id_next = (unsigned)tid < nl ? v.list[tid] : 0u;
+        for (unsigned t = (unsigned)tid; t < nl; t += (unsigned)g.nt) {
+            const unsigned id = id_next;
+            if (t + (unsigned)g.nt < nl) id_next = v.list[t + (unsigned)g.nt];     // in flight during tile_min
+            const int rq = (int)(id >> 8), gpl = (int)(id & 255u);
+            const float val = tile_min<Q>(v.Xq, v.Yq, v.Eq, rq, g.wc + g.CS * gpl);
+            const unsigned kv = fkey(val);
+            v.Mc[rq * g.GPl + gpl] = kv;
+            const int seg = (int)(((float)rq + 0.5f) * inv_ms2);         // rq / MS2 (exact: rq <= 255, MS2 <= 32)
+            atomicMin(&v.Mu[seg * g.GPl + gpl], kv);
+        }
+        FINE(pf, 1);
+    }
+    __builtin_amdgcn_s_setprio(3);
+    if (tid == 0) {     // the pair (0, n-1): cyclically adjacent, not on any walked diagonal
+        const int n = g.n;
+        if (last == kFullSweep || (last >> 16) == 0u || (last & 0xffffu) == (unsigned)(n - 1)) {
+            const int s0 = slot<Q>(0), s1 = slot<Q>(1), sn1 = slot<Q>(n - 1), sn = slot<Q>(n);
+            const float d0 = dist32(v.Xq[s0].x, v.Yq[s0].x, v.Xq[sn1].x, v.Yq[sn1].x);
+            const float d1 = dist32(v.Xq[s1].x, v.Yq[s1].x, v.Xq[sn].x, v.Yq[sn].x);
+            ctl->spd = ((d0 + d1) - v.Eq[sn1].x) - v.Eq[s0].x;
+        }
+    }
 }
 
 // window position -> tour position; window positions are below 3n (make_plan guarantees W < 3n)
@@ -306,7 +396,29 @@ __device__ __forceinline__ void filter_chunk_pair(const View<T>& v, const Geo& g
     idx = ((unsigned)i << 16) | (unsigned)j;
 }
 
-// One full argmin (the reference's per-tour torch.min / torch.argmin, two_opt.py:35-38).
+// filter_chunk_pair with every LDS read issued before the first use (one round trip instead of six)
+template <int Q, typename T>
+__device__ __forceinline__ void filter_chunk_pair_b(const View<T>& v, const Geo& g, unsigned id, int pr,
+                                                    float& d, unsigned& idx)
+{
+    int rw, cw;
+    tile_pair(g, id, pr, rw, cw);
+    const int sr = slot<Q>(rw), sr1 = slot<Q>(rw + 1), sc = slot<Q>(cw), sc1 = slot<Q>(cw + 1);
+    const float xr = v.Xq[sr].x, yr = v.Yq[sr].x, xc = v.Xq[sc].x, yc = v.Yq[sc].x;
+    const float xr1 = v.Xq[sr1].x, yr1 = v.Yq[sr1].x, xc1 = v.Xq[sc1].x, yc1 = v.Yq[sc1].x;
+    const float ec = v.Eq[sc].x, er = v.Eq[sr].x;
+    asm volatile("" ::"v"(xr), "v"(yr), "v"(xc), "v"(yc), "v"(xr1), "v"(yr1), "v"(xc1), "v"(yc1), "v"(ec), "v"(er));
+    const float d0 = dist32(xr, yr, xc, yc);
+    const float d1 = dist32(xr1, yr1, xc1, yc1);
+    d = ((d0 + d1) - ec) - er;
+    const int r = wrap3(rw, g.n), c = wrap3(cw, g.n);
+    const int i = r < c ? r : c, j = r < c ? c : r;
+    idx = ((unsigned)i << 16) | (unsigned)j;
+}
+
+// One full argmin (the reference's per-tour torch.min / torch.argmin, two_opt.py:35-38) for geometries
+// WITHOUT the tile cache (tiny tours with one tile per lane; N where the cache does not fit) and the
+// exact-only kernel (Q = 0); select_cached below is the same decision on top of the cache.
 // Returns in every thread: e = min(0, min valid delta), idx = packed (i,j) or kNoMove.
 // `need_exact_sign`: the caller needs the exact sign of a non-improving minimum (coupled-mode
 // continuation); otherwise a minimum proven >= -1e-6 by the filter alone ends the search.
@@ -332,7 +444,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
         // everything outside the sweep arithmetic is a latency chain that idles most of the
         // workgroup: it runs at high issue priority (set inside sweep()) so that the other
         // workgroups' sweeps on this SIMD do not stretch it
-        sweep<Q, CL>(v, g, tid, last, a1, a2, chunk, pf);
+        sweep<Q, CL>(v, g, tid, a1, a2, chunk, pf);
         if (pf.on) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
         const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
         const float wm = wave_min(a1);
@@ -486,50 +598,278 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
         }
         if (amb) {
             // A lane holds two tiles inside the window (or a wave more than 8 candidates): the per-lane
-            // best/runner-up no longer names every candidate.  With the tile cache, every candidate is
-            // still known -- all tiles whose cached minimum is inside the window -- and is evaluated
-            // exactly, one tile per wave at a time; only without the cache (or if even that list
-            // overflows: heavy ties, e.g. grids) the whole tour is swept exactly.
+            // best/runner-up no longer names every candidate and there is no tile cache to list them
+            // from: the whole tour is swept exactly.
             __syncthreads();
-            bool listed = false;
-            if (g.inc) {
-                const int tiles = g.GPl * g.NS * (g.MS >> 1);
-                for (int t = tid; t < tiles; t += g.nt) {
-                    const int gpl = t % g.GPl;
-                    if (v.Mc[t] <= thr && g.wc + g.CS * gpl < g.GP) {
-                        const unsigned pos = atomicAdd(&ctl->nlist, 1u);
-                        if (pos < (unsigned)g.lcap) v.list[pos] = (uint16_t)(((unsigned)(t / g.GPl) << 8) | (unsigned)gpl);
-                    }
-                }
-                __syncthreads();
-                const unsigned nl = ctl->nlist;
-                __syncthreads();
-                if (tid == 0) ctl->nlist = 0;
-                if (nl <= (unsigned)g.lcap) {
-                    listed = true;
-                    e = 0.0;
-                    idx = kNoMove;
-                    for (unsigned c = (unsigned)wv; c < nl; c += (unsigned)nw) {
-                        double d;
-                        unsigned di;
-                        eval_chunk_pair(v, g, v.list[c], lane, d, di);
-                        if (better(d, di, e, idx)) { e = d; idx = di; }
-                    }
-                    if (tid == 0) {
-                        const double d = exact_delta(v, 0, g.n - 1);
-                        if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
-                    }
-                    block_best(ctl, tid, g.nt, e, idx);
-                }
-            }
-            if (!listed) {
-                exact_sweep(v, g.n, tid, g.nt, e, idx);
-                block_best(ctl, tid, g.nt, e, idx);
-            }
+            exact_sweep(v, g.n, tid, g.nt, e, idx);
+            block_best(ctl, tid, g.nt, e, idx);
         }
         FINE(pf, 7);                                        // exact stage
         if (pf.on) pf.select += clock64() - t0;
     }
+}
+
+// The unit minima of this workgroup, held by a wave: lane l keeps units 256c + 4l .. 256c + 4l + 3 of
+// chunk c (one 16-byte LDS read per chunk; Mu is padded to a multiple of 4 with "+inf" keys).
+struct UnitMinima {
+    uint4 k[4];             // up to 1024 units
+    int nch;
+};
+
+template <typename T>
+__device__ __forceinline__ UnitMinima load_unit_minima(const View<T>& v, const Geo& g, int lane)
+{
+    UnitMinima um;
+    const int units = g.GPl * g.NS;
+    um.nch = (units + 255) >> 8;
+    const uint4 inf = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        um.k[c] = inf;
+        if (c < um.nch && 256 * c + 4 * lane < units)
+            um.k[c] = *reinterpret_cast<const uint4*>(v.Mu + 256 * c + 4 * lane);
+    }
+    return um;
+}
+
+__device__ __forceinline__ unsigned unit_minimum(const UnitMinima& um)
+{
+    unsigned km = 0xffffffffu;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c < um.nch) {
+            const unsigned a = um.k[c].x < um.k[c].y ? um.k[c].x : um.k[c].y;
+            const unsigned b = um.k[c].z < um.k[c].w ? um.k[c].z : um.k[c].w;
+            const unsigned m = a < b ? a : b;
+            km = m < km ? m : km;
+        }
+    }
+    return wave_min_u32(km);
+}
+
+// Visit every tile of this workgroup whose cached minimum is <= thr: a wave-uniform loop, f(id) runs
+// with all 64 lanes.  Returns the number of tiles visited, or -1 as soon as more than max_tiles are
+// inside the window (heavy ties; the caller falls back to the cooperative listing).
+template <typename T, typename F>
+__device__ __forceinline__ int for_each_candidate_tile(const View<T>& v, const Geo& g, int lane, float thr,
+                                                       const UnitMinima& um, int max_tiles, F&& f)
+{
+    const int MS2 = g.MS >> 1;
+    const unsigned kthr = fkey(thr);
+    int count = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= um.nch) break;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned key = k == 0 ? um.k[c].x : k == 1 ? um.k[c].y : k == 2 ? um.k[c].z : um.k[c].w;
+            unsigned long long ub = __ballot(key <= kthr);
+            while (ub) {
+                const int u = 256 * c + 4 * __builtin_amdgcn_readfirstlane(__ffsll((long long)ub) - 1) + k;
+                ub &= ub - 1;
+                const int s = u / g.GPl, gpl = u - s * g.GPl;
+                const int rq0 = s * MS2;
+                const unsigned cm = v.Mc[(rq0 + (lane < MS2 ? lane : MS2 - 1)) * g.GPl + gpl];
+                unsigned long long tb = __ballot(lane < MS2 && cm <= kthr);
+                while (tb) {
+                    const int m2 = __builtin_amdgcn_readfirstlane(__ffsll((long long)tb) - 1);
+                    tb &= tb - 1;
+                    if (count >= max_tiles) return -1;
+                    ++count;
+                    f(((unsigned)(rq0 + m2) << 8) | (unsigned)gpl);
+                }
+            }
+        }
+    }
+    return count;
+}
+
+constexpr int kStage1Tiles = 8;     // more candidate tiles than this: heavy ties, cooperative path
+
+// window of the filter values that can hold the argmin, from the unit minima (every lane of a wave)
+template <bool CL>
+__device__ __forceinline__ float window_threshold(const UnitMinima& um, const Geo& g, float thr_scale, float eps,
+                                                  float& m)
+{
+    m = funkey(unit_minimum(um));
+    float thr = m + g.eps2;
+    // CL: this workgroup sees only its own tiles, whose minimum may be far above the tour's.  Only moves
+    // below -1e-6 are ever applied (independent termination), so pairs whose filter value proves
+    // delta >= -1e-6 need no exact evaluation.
+    if constexpr (CL) thr = fminf(thr, -thr_scale + eps);
+    return thr;
+}
+
+// Phase C of the cached path: the argmin decision from Mu / Mc / the window (see the header of this
+// section).  One workgroup per tour: ONE wave (rotating with `round`) decides and posts the result in
+// LDS; the barrier that follows both publishes it and marks the end of all reads of the window, so
+// the reversal may start right after it.  CL: every wave decides redundantly (clusters run at low
+// occupancy, the redundancy is free) and the cluster exchange's barrier plays that role.
+// Same contract as find_best: in every thread e = min(0, min valid delta) (or a certified upper bound
+// below -1e-6 for a certain move), idx = packed (i,j) or kNoMove.  CL: this workgroup's tiles only,
+// always exact (the result is compared across workgroups).
+template <typename T, int Q, bool CL>
+__device__ void select_cached(const View<T>& v, const Geo& g, int tid, bool need_exact_sign, int round,
+                              double& e, unsigned& idx, Prof& pf)
+{
+    Ctl* ctl = v.ctl;
+    const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
+    const float eps = 0.625f * g.eps2;                  // eps2 = 2 eps; 25 % extra margin
+    const bool mine = CL || nw == 1 || wv == round % nw;
+    int code = 0;                                       // 0: (e, idx) final, 1: exact stage, 2: heavy ties
+    e = 0.0;
+    idx = kNoMove;
+    FINE_START(pf);
+    if (mine) {
+        const UnitMinima um = load_unit_minima(v, g, lane);     // one LDS round trip together with sc / spd
+        const double scale = ctl->sc;
+        const float spd = ctl->spd;
+        const float thr_scale = (float)(1.0e-6 * scale);
+        float m;
+        const float thr = window_threshold<CL>(um, g, thr_scale, eps, m);
+        FINE(pf, 4);                                    // workgroup minimum of the filter
+        if constexpr (CL) {
+            const int nct = for_each_candidate_tile(v, g, lane, thr, um, kStage1Tiles, [&](unsigned id) {
+                double d;
+                unsigned di;
+                eval_chunk_pair(v, g, id, lane, d, di);
+                if (better(d, di, e, idx)) { e = d; idx = di; }
+            });
+            if (nct >= 0) {
+                // the pair (0, n-1): its filter value gates the exact evaluation exactly like a tile's minimum
+                if (spd <= thr) {                       // (uniform)
+                    const double d = exact_delta(v, 0, g.n - 1);
+                    if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
+                }
+                wave_best(e, idx);
+            } else {
+                code = 2;
+            }
+        } else {
+            // ---- stage 1, fp32 only.  Every pair whose exact delta can be the argmin has a filter value
+            // <= m + 2 eps and sits in a tile whose cached minimum is inside that window.  Re-evaluate those
+            // tiles pair by pair in fp32 (lane = pair): if exactly ONE pair of the whole tour is inside the
+            // window it IS the reference's argmin, and if its value is below -1e-6 by more than eps the move
+            // is certain without any exact arithmetic.  Likewise a window that lies above -1e-6 + eps proves
+            // convergence.  Anything else goes to the exact stage.
+            float fd = INFINITY;
+            unsigned fidx = 0xffffffffu;
+            bool multi = false;
+            const int nct = for_each_candidate_tile(v, g, lane, thr, um, kStage1Tiles, [&](unsigned id) {
+                float d;
+                unsigned di;
+                filter_chunk_pair_b<Q>(v, g, id, lane, d, di);
+                if (d <= thr) {
+                    multi = multi || (fidx != 0xffffffffu && fidx != di);
+                    if (d < fd || (d == fd && di < fidx)) { fd = d; fidx = di; }
+                }
+            });
+            if (nct < 0) {
+                code = 2;
+            } else {
+                if (lane == 0) {
+                    const unsigned di = (unsigned)(g.n - 1);
+                    if (spd <= thr) {
+                        multi = multi || (fidx != 0xffffffffu && fidx != di);
+                        if (spd < fd || (spd == fd && di < fidx)) { fd = spd; fidx = di; }
+                    }
+                }
+                FINE(pf, 5);                            // fp32 re-evaluation of the candidate tiles
+                const unsigned long long hm = __ballot(fidx != 0xffffffffu);
+                const float wd = wave_min(fd);
+                unsigned widx = 0xffffffffu;
+                if (hm) widx = (unsigned)__builtin_amdgcn_readlane((int)fidx, __ffsll((long long)hm) - 1);
+                const bool wother = __ballot(multi || (fidx != 0xffffffffu && fidx != widx)) != 0ull;
+                const bool unique = !wother && widx != 0xffffffffu;
+                code = 1;
+                if (unique && wd < -thr_scale - eps) {                  // certain improving move
+                    e = ((double)wd + (double)eps) / scale;             // an upper bound, < -1e-6
+                    idx = widx;
+                    code = 0;
+                } else if (!need_exact_sign && m > -thr_scale + eps &&
+                           (widx == 0xffffffffu || wd > -thr_scale + eps)) {
+                    e = 0.0;                                            // proven: no delta below -1e-6
+                    idx = kNoMove;
+                    code = 0;
+                }
+                FINE(pf, 6);
+            }
+        }
+    }
+    if constexpr (!CL) {
+        if (nw > 1) {
+            if (mine && lane == 0) { ctl->bestE = e; ctl->bestIdx = idx; ctl->ambiguous = code; }
+            __syncthreads();            // the decision is out AND nobody reads the window any more
+            e = ctl->bestE;
+            idx = ctl->bestIdx;
+            code = ctl->ambiguous;
+            FINE(pf, 9);
+        }
+    }
+    if (code == 0) return;              // (uniform: CL waves all computed the same code)
+
+    // ---- exact stage, cooperative: every wave rebuilds the window from the same LDS words
+    const bool heavy = code == 2;
+    if (pf.on) { pf.cands += 1; pf.amb += heavy ? 1 : 0; }
+    const UnitMinima um = load_unit_minima(v, g, lane);
+    float m;
+    const float thr = window_threshold<CL>(um, g, (float)(1.0e-6 * ctl->sc), eps, m);
+    e = 0.0;
+    idx = kNoMove;
+    if (!heavy) {
+        // each wave takes every nw-th candidate tile, reference dtype and operation order (lane = pair)
+        int c = 0;
+        for_each_candidate_tile(v, g, lane, thr, um, 1 << 30, [&](unsigned id) {
+            if (c++ % nw == wv) {
+                double d;
+                unsigned di;
+                eval_chunk_pair(v, g, id, lane, d, di);
+                if (better(d, di, e, idx)) { e = d; idx = di; }
+            }
+        });
+        if (tid == 0) {
+            const double d = exact_delta(v, 0, g.n - 1);
+            if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
+        }
+        block_best(ctl, tid, g.nt, e, idx);
+    } else {
+        // heavy ties (regular grids): list every tile inside the window cooperatively and evaluate the
+        // list exactly, one tile per wave at a time; if even the list overflows, sweep the tour exactly
+        __syncthreads();                                // nlist was zeroed after the phase B barrier
+        bool listed = false;
+        const int tiles = g.GPl * g.NS * (g.MS >> 1);
+        const unsigned kthr = fkey(thr);
+        for (int t = tid; t < tiles; t += g.nt) {
+            const int gpl = t % g.GPl;
+            if (g.wc + g.CS * gpl < g.GP && v.Mc[t] <= kthr) {
+                const unsigned pos = atomicAdd(&ctl->nlist, 1u);
+                if (pos < (unsigned)g.lcap) v.list[pos] = (uint16_t)(((unsigned)(t / g.GPl) << 8) | (unsigned)gpl);
+            }
+        }
+        __syncthreads();
+        const unsigned nl = ctl->nlist;
+        __syncthreads();
+        if (tid == 0) ctl->nlist = 0;
+        if (nl <= (unsigned)g.lcap) {
+            listed = true;
+            for (unsigned c = (unsigned)wv; c < nl; c += (unsigned)nw) {
+                double d;
+                unsigned di;
+                eval_chunk_pair(v, g, v.list[c], lane, d, di);
+                if (better(d, di, e, idx)) { e = d; idx = di; }
+            }
+            if (tid == 0) {
+                const double d = exact_delta(v, 0, g.n - 1);
+                if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
+            }
+            block_best(ctl, tid, g.nt, e, idx);
+        }
+        if (!listed) {
+            exact_sweep(v, g.n, tid, g.nt, e, idx);
+            block_best(ctl, tid, g.nt, e, idx);
+        }
+    }
+    FINE(pf, 7);                                        // exact stage
 }
 
 // write the filter copy of position p: every window index w = p (mod n) is the A value of entry
@@ -591,44 +931,48 @@ __device__ __forceinline__ void put_e(const View<T>& v, const Geo& g, int p, flo
     }
 }
 
-// reverse tour[i+1..j] (two_opt.py:42) and keep the filter window consistent
+// reverse tour[i+1..j] (two_opt.py:42) and keep the filter window consistent.  Every lane first loads
+// everything its swap needs (two positions with their coordinates, two interior edges) and only then
+// writes, so the LDS round trips of the phase overlap; the caller closes the phase with a barrier.
 template <typename T, int Q>
-__device__ void apply_move(const View<T>& v, const Geo& g, int tid, unsigned idx, Prof& pf)
+__device__ __forceinline__ void apply_move(const View<T>& v, const Geo& g, int tid, unsigned idx, Prof& pf)
 {
     const int i = (int)(idx >> 16), j = (int)(idx & 0xffffu);
     FINE_START(pf);
-
     const int L = j - i;
-    const int h = L >> 1;
+    const int h = L >> 1;                       // position swaps
+    const int he = (L - 1) >> 1;                // interior edges i+1..j-1 are mirrored (he <= h)
     for (int k = tid; k < h; k += g.nt) {
         const int p = i + 1 + k, p2 = j - k;
         const uint16_t ta = v.tour[p], tb = v.tour[p2];
-        v.tour[p] = tb;
-        v.tour[p2] = ta;
         if constexpr (Q != 0) {
             const int sp = slot<Q>(p), sp2 = slot<Q>(p2);
             const float ax = v.Xq[sp].x, ay = v.Yq[sp].x, bx = v.Xq[sp2].x, by = v.Yq[sp2].x;
+            const bool ed = k < he;
+            float ea = 0.f, eb = 0.f, lx = 0.f, ly = 0.f, rx = 0.f, ry = 0.f;
+            if (ed) { ea = v.Eq[sp].x; eb = v.Eq[slot<Q>(p2 - 1)].x; }
+            if (k == 0) {                       // p = i+1, p2 = j: the neighbours outside the segment
+                lx = v.Xq[slot<Q>(i)].x; ly = v.Yq[slot<Q>(i)].x;
+                rx = v.Xq[slot<Q>(j + 1)].x; ry = v.Yq[slot<Q>(j + 1)].x;
+            }
+            v.tour[p] = tb;
+            v.tour[p2] = ta;
             put_xy<Q>(v, g, p, bx, by);
             put_xy<Q>(v, g, p2, ax, ay);
-            if (k == 0) {   // p = i+1, p2 = j: the two new boundary edges
-                put_e<Q>(v, g, i, dist32(v.Xq[slot<Q>(i)].x, v.Yq[slot<Q>(i)].x, bx, by));
-                put_e<Q>(v, g, j, dist32(ax, ay, v.Xq[slot<Q>(j + 1)].x, v.Yq[slot<Q>(j + 1)].x));
+            if (ed) {
+                put_e<Q>(v, g, p, eb);
+                put_e<Q>(v, g, p2 - 1, ea);
             }
+            if (k == 0) {                       // the two new boundary edges
+                put_e<Q>(v, g, i, dist32(lx, ly, bx, by));
+                put_e<Q>(v, g, j, dist32(ax, ay, rx, ry));
+            }
+        } else {
+            v.tour[p] = tb;
+            v.tour[p2] = ta;
         }
     }
-    FINE(pf, 8);                                // positions + coordinates + boundary edges
-    if constexpr (Q != 0) {
-        const int he = (L - 1) >> 1;            // interior edges i+1..j-1 are mirrored
-        for (int k = tid; k < he; k += g.nt) {
-            const int p = i + 1 + k, p2 = j - 1 - k;
-            const float a = v.Eq[slot<Q>(p)].x, b = v.Eq[slot<Q>(p2)].x;
-            put_e<Q>(v, g, p, b);
-            put_e<Q>(v, g, p2, a);
-        }
-    }
-    FINE(pf, 9);                                // interior edges
-    __syncthreads();
-    FINE(pf, 10);                               // closing barrier
+    FINE(pf, 8);                                // positions + coordinates + edges
 }
 
 // ------------------------------------------------------------------------------------------
@@ -699,6 +1043,54 @@ __device__ bool cluster_exchange(Ctl* ctl, unsigned* cs, int CS, int wc, unsigne
     return ok;
 }
 
+// The same exchange for the full-window cluster (CS <= 64): after the one barrier that follows the
+// wait, EVERY wave reads all CS slots itself (lane = slot) and reduces them with DPP, so all waves hold
+// the same winner without a second trip through LDS.  That barrier also separates the waves' reads of
+// the filter window (move selection) from the writes of the reversal that follows.
+__device__ bool cluster_exchange_w(Ctl* ctl, unsigned* cs, int CS, int wc, unsigned epoch, int tid,
+                                   unsigned flags_in, double& e, unsigned& idx, unsigned& flags_out)
+{
+    if (tid == 0) {
+        unsigned* slot = cs + 16 + ((epoch & 1u) * (unsigned)CS + (unsigned)wc) * kSlotDw;
+        __hip_atomic_store(slot + 0, (unsigned)__double2loint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 1, (unsigned)__double2hiint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 2, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 3, flags_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(cs, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned want = (unsigned)CS * (epoch + 1u);
+        unsigned spins = 0;
+        bool ok = true;
+        while (__hip_atomic_load(cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit ||
+                __hip_atomic_load(cs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(cs + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        ctl->ambiguous = ok ? 0 : 1;        // reused as the abort flag
+    }
+    __syncthreads();
+    const bool ok = ctl->ambiguous == 0;
+    const int lane = tid & 63;
+    e = 0.0;
+    idx = kNoMove;
+    unsigned fl = 0;
+    if (ok && lane < CS) {
+        const unsigned* sl = cs + 16 + ((epoch & 1u) * (unsigned)CS + (unsigned)lane) * kSlotDw;
+        const unsigned lo = __hip_atomic_load(sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned hi = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        idx = __hip_atomic_load(sl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fl = __hip_atomic_load(sl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        e = __hiloint2double((int)hi, (int)lo);
+    }
+    wave_best(e, idx);
+    flags_out = __ballot(fl != 0u) != 0ull ? 1u : 0u;
+    return ok;
+}
+
 constexpr unsigned kFlagStop = 1u;      // published by workgroup 0: wall-clock limit reached
 
 // ------------------------------------------------------------------------------------------
@@ -751,12 +1143,15 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
     off += sizeof(v2f) * 8 * (size_t)Q;
     v.Mc = nullptr;
     v.list = nullptr;
+    v.Mu = nullptr;
     if (g.inc) {
         const size_t tiles = (size_t)g.GPl * g.NS * (g.MS >> 1);
-        v.Mc = reinterpret_cast<float*>(smem + off);
+        v.Mc = reinterpret_cast<unsigned*>(smem + off);
         off += align16(sizeof(float) * tiles);
         v.list = reinterpret_cast<uint16_t*>(smem + off);
         off += align16(sizeof(uint16_t) * (size_t)g.lcap);
+        v.Mu = reinterpret_cast<unsigned*>(smem + off);
+        off += align16(sizeof(unsigned) * (size_t)(g.GPl * g.NS));    // (padded to a multiple of 4 entries)
     }
     T* xl = reinterpret_cast<T*>(smem + off);
     Ctl* ctl = v.ctl;
@@ -775,7 +1170,7 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
         if (tk >= p.num_tours) break;          // uniform exit: every wave leaves here
 
         const int64_t grp = tk / p.group_size;
-        Prof pf{p.stamps != nullptr, 0, 0, 0};
+        Prof pf = make_prof(p.stamps);
         const unsigned long long t_tour = pf.on ? clock64() : 0;
         int it = 0, target = 0;
         if (p.mode == kModeForced) {
@@ -866,6 +1261,8 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
                 const v2f x0 = v.Xq[s0], y0 = v.Yq[s0], x1 = v.Xq[s1], y1 = v.Yq[s1];
                 v.Eq[s0] = (v2f){dist32(x0.x, y0.x, x1.x, y1.x), dist32(x0.y, y0.y, x1.y, y1.y)};
             }
+            if (g.inc)          // units without a lane group (cluster padding) never get a minimum
+                for (int u = tid; u < ((g.GPl * g.NS + 3) & ~3); u += nt) v.Mu[u] = 0xffffffffu;
         }
         __syncthreads();
 
@@ -881,7 +1278,7 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
                 for (int k = 0; k < p.dbg_sweeps; ++k) {
                     float a1, a2;
                     unsigned chunk;
-                    filter_sweep<Q, CL>(v.Xq, v.Yq, v.Eq, v.Mc, g, tid, a1, a2, chunk);
+                    filter_sweep<Q, CL>(v.Xq, v.Yq, v.Eq, nullptr, g, tid, a1, a2, chunk);
                     acc += a1 + a2 + (float)chunk;
                     asm volatile("" ::: "memory");
                 }
@@ -901,17 +1298,39 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
         bool have_prev = false, prev_active = false, active_at_target = false;
         unsigned prev_idx = kNoMove;
         unsigned last = kFullSweep;             // reversal applied since the previous sweep
+        const int tid_fixed = tid;
         for (;;) {
+            // The kernel sits at its VGPR limit.  Left alone, the compiler hoists everything that is
+            // derived from the thread index (unit, LDS addresses, conversion constants) out of this loop
+            // and then spills it to scratch, paying a memory round trip per use; an opaque copy of the
+            // index per iteration makes those values loop-variant, i.e. recomputed where they are used.
+            int tid = tid_fixed;
+            asm volatile("" : "+v"(tid));
             const bool check_only = forced && it >= target;
             if (check_only && target >= p.max_iter) break;
-            find_best<T, Q, CL>(v, g, tid, forced, last, e, idx, pf);
+            bool cached = false;
+            if constexpr (Q != 0) cached = g.inc != 0;          // (uniform)
+            if constexpr (Q != 0) {
+                if (cached) {
+                    unsigned long long t0 = 0;
+                    if (pf.on) t0 = clock64();
+                    refresh_cached<Q, CL>(v, g, tid, last, pf);                 // phase B
+                    __syncthreads();
+                    FINE(pf, 2);                                                // barrier after the refresh
+                    if (tid == 0) ctl->nlist = 0;
+                    if (pf.on) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
+                    select_cached<T, Q, CL>(v, g, tid, forced, sweeps, e, idx, pf);    // phase C
+                    if (pf.on) pf.select += clock64() - t0;
+                }
+            }
+            if (!cached) find_best<T, Q, CL>(v, g, tid, forced, last, e, idx, pf);
             ++sweeps;
             unsigned xfl = 0;
             if constexpr (CL) {
                 unsigned myflags = 0;
                 if (g.wc == 0 && p.time_limit_ticks && wall_clock64() - t_start > p.time_limit_ticks)
                     myflags |= kFlagStop;
-                if (!cluster_exchange(ctl, cs, g.CS, g.wc, epoch, tid, nt, myflags, e, idx, xfl)) {
+                if (!cluster_exchange_w(ctl, cs, g.CS, g.wc, epoch, tid, myflags, e, idx, xfl)) {
                     st = TSP2OPT_ST_INTERNAL;
                     break;
                 }
@@ -935,7 +1354,16 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
             }
             unsigned long long ta = 0;
             if (pf.on) ta = clock64();
-            apply_move<T, Q>(v, g, tid, idx, pf);
+            // (cached path: select_cached / the cluster exchange ended with the barrier after which nobody
+            //  reads the window any more)
+            FINE_START(pf);
+            apply_move<T, Q>(v, g, tid, idx, pf);               // phase A
+            if constexpr (Q != 0) {
+                if (cached) mark_touched<CL>(v, g, tid, idx);
+            }
+            FINE(pf, 0);                                        // marking + compaction
+            __syncthreads();
+            FINE(pf, 10);                                       // closing barrier
             last = idx;
             if (pf.on) pf.apply += clock64() - ta;
             if (stop_after) break;
@@ -977,6 +1405,7 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
                 atomicAdd(&p.stamps[4], clock64() - t_tour);
                 atomicAdd(&p.stamps[5], (unsigned long long)pf.amb);
                 atomicAdd(&p.stamps[6], (unsigned long long)pf.cands);
+                atomicAdd(&p.stamps[7], pf.candcyc);
 #ifdef TSP2OPT_FINE
                 for (int k = 0; k < 16; ++k) atomicAdd(&p.stamps[8 + k], pf.fine[k]);
 #endif

@@ -29,7 +29,7 @@ t1.record(); torch.cuda.synchronize()
 ws = list(two_opt._workspaces.values())[0]
 st = ws[64:128].cpu().numpy().view(np.uint64)
 fine = ws[128:256].cpu().numpy().view(np.uint64)
-print('amb events:', int(st[5]), 'exact-stage runs (single-WG) / wave0 cands (cluster)', int(st[6]), 'sweeps', int(res.sweeps.sum().item()))
+print('candidate tiles visited:', int(st[7]), 'amb events:', int(st[5]), 'exact-stage runs (single-WG) / wave0 cands (cluster)', int(st[6]), 'sweeps', int(res.sweeps.sum().item()))
 names = ["sweep", "select", "apply", "stage/exchange", "tour_total"]
 tot = float(st[4])
 sw = int(res.sweeps.sum().item())
@@ -37,9 +37,10 @@ print(f"{cfg} {dt.__name__}: {t0.elapsed_time(t1):.2f} ms (stamped build), plan=
 for n, v in zip(names, st):
     print(f"  {n:10s} {int(v):>16d} cycles  {100*float(v)/tot:6.2f} %   per sweep: {float(v)/sw:9.1f}")
 if fine.any():      # TSP2OPT_LIB=.../libtsp2opt_hip_fine.so (python -m ml4tspbench_amd.build --fine)
-    labels = ["sweep: mark+compact", "sweep: barrier+changed tiles", "sweep: barrier+cached minima", "sweep: full",
-              "select: wg filter min", "select: fp32 candidates", "select: fp32 reduction", "select: exact stage",
-              "apply: positions+coords", "apply: interior edges", "apply: barrier", "cluster exchange"]
+    labels = ["A: mark+compact", "B: listed tiles", "B: closing barrier", "B: full sweep",
+              "C: unit minima scan", "C: fp32 candidates", "C: decision", "C: exact stage",
+              "A: reversal", "A: opening barrier", "A: closing barrier", "cluster exchange",
+              "C: candidate discovery", "C: fp32 pairs of candidate tiles", "-", "-"]
     for n, v in zip(labels, fine):
         print(f"    {n:32s} per sweep: {float(v)/sw:9.1f}")
 L.tsp2opt_debug_phase_cycles(0)
