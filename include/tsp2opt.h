@@ -222,7 +222,10 @@ int tsp2opt_debug_cluster_inc(int32_t on);
  * tile-minimum cache to be used (default 2); what = 3: cluster kernel variant, 0 automatic, 1 band
  * kernel only, 2 full-window kernel only; what = 4: changed-tile list capacity of the one-workgroup /
  * full-window kernels in sixteenths of the tiles (default 13); what = 5: unused LDS bytes added to the
- * one-workgroup kernel's request (lowers the workgroups resident per CU: occupancy sweeps; default 0). */
+ * one-workgroup kernel's request (lowers the workgroups resident per CU: occupancy sweeps; default 0);
+ * what = 6: 1 replays coupled calls (group_size > 1) entirely in the lock-step kernel (tests; default 0);
+ * what = 7: band cluster kernel, log2 of the macro steps per part when a listed cache group is recomputed
+ * (default 3).  The knobs belong to the calling thread. */
 int tsp2opt_debug_tune(int32_t what, int32_t value);
 /* Geometry the library would pick for `num_tours` tours of n nodes on a device with `cus` compute
  * units when several workgroups share a tour (host-only, for logs and tests):

@@ -102,6 +102,7 @@ struct Opts {
     int cluster_mode = -1;      // -1 auto, 0 never, >= 2 force that many workgroups per tour (tests)
     int cluster_variant = 0;    // 0 auto, 1 band kernel only (k_two_opt_cluster), 2 full-window kernel only
     int force_lockstep = 0;     // coupled mode: replay the whole call in k_group_lockstep (tests)
+    int part_sh = 3;            // band cluster: listed groups are recomputed in parts of at most 2^part_sh macro steps
 };
 thread_local Opts t_opts;
 
@@ -429,9 +430,18 @@ CPlan make_cluster_plan(const Opts& o, int n, int dtype, int cs_cap, bool smalle
                 const int units = GPw * NSw;
                 const int passes = (units + nt - 1) / nt;
                 const int wps = (nt / 64 + 3) / 4;      // waves per SIMD
-                const int Qw = NSw * MS + 2 * GPw + 3;
                 const int rowsw = 4 * NSw * MS;
-                size_t lds = base + (size_t)Qw * 96 + 3 * align16(sizeof(float) * (size_t)(rowsw + 8));
+                // cr == 1: every workgroup walks all rows -> rows and columns share one copy of the tour
+                // (positions [0, n + 12), indices wrapping at n / 4 groups) when 4 divides n, else the window
+                // is extended to the last walked column; cr > 1: column window of the tile + row band arrays
+                const bool shared = cr == 1;
+                const bool wrap = shared && n % 4 == 0;
+                int Qw;
+                if (wrap) Qw = n / 4 + 4;
+                else if (shared) Qw = NSw * MS + 2 * GP + 4;
+                else Qw = NSw * MS + 2 * GPw + 4;
+                size_t lds = base + 3 * align16((size_t)Qw * 16) +
+                             (shared ? 0 : 3 * align16(sizeof(float) * (size_t)(rowsw + 8)));
                 if (lds > kLdsMax) continue;
                 // group-minimum cache: the finest granularity K (macro steps per entry) that fits
                 int K = 0, Ksh = 0, NG = MS, lcap = 0;
@@ -448,15 +458,23 @@ CPlan make_cluster_plan(const Opts& o, int n, int dtype, int cs_cap, bool smalle
                         }
                     }
                 }
-                // measured: incremental sweeps recompute a little under half of the pairs
-                const double t_iter = (K ? 0.55 : 1.0) * 0.4 * MS * passes * wps + 12.0 + 0.15 * cs;
+                // measured: incremental sweeps recompute a little under half of the pairs -- of the SLOWEST
+                // workgroup: with row bands (cr > 1) one band usually lies inside the reversed segment and
+                // recomputes nearly everything while the others wait for it
+                const double t_iter = (K ? (cr > 1 ? 0.8 : 0.55) : 1.0) * 0.4 * MS * passes * wps + 12.0 + 0.15 * cs;
                 const double cost = smallest ? t_iter * cs : t_iter;    // total WG-time vs latency
                 if (cost >= best_cost) continue;
                 lds += cache;
                 CGeo g{};
                 g.n = n; g.nt = nt; g.GP = GP; g.CS = cs; g.CR = cr; g.CD = cd;
                 g.GPw = GPw; g.NSw = NSw; g.MS = MS; g.Qw = Qw; g.rowsw = rowsw;
+                g.sh = shared ? 1 : 0; g.wrapg = wrap ? n / 4 : 0x3fffffff;
                 g.K = K ? K : 1; g.Ksh = K ? Ksh : 2; g.NG = NG; g.inc = K ? 1 : 0; g.lcap = lcap;
+                {   // parts of at most 2^part_sh macro steps (the restart of a part costs about one macro step)
+                    int psh = 0;
+                    while ((2 << psh) <= g.K && psh < o.part_sh) ++psh;
+                    g.Psh = psh;
+                }
                 g.eps2 = dtype == TSP2OPT_DTYPE_F64 ? 2.0f * 0x1p-16f : 2.0f * 0x1p-15f;
                 g.xlds = 0;
                 if (lds + align16(xbytes) <= kLdsMax) { g.xlds = 1; lds += align16(xbytes); }
@@ -941,6 +959,7 @@ extern "C" int tsp2opt_debug_tune(int32_t what, int32_t value)
     else if (what == 4) o.lcap16s = value < 1 ? 1 : value > 16 ? 16 : value;
     else if (what == 5) o.lds_pad = value < 0 ? 0 : value;
     else if (what == 6) o.force_lockstep = value ? 1 : 0;
+    else if (what == 7) o.part_sh = value < 0 ? 0 : value > 6 ? 6 : value;
     else return fail(TSP2OPT_E_ARG, "unknown tuning knob");
     return 0;
 }

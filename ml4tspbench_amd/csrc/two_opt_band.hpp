@@ -9,8 +9,16 @@ namespace t2o {
 // ------------------------------------------------------------------------------------------
 // The (row segment x diagonal group) rectangle of one tour is tiled over CS = CR x CD workgroups.
 // Every workgroup keeps the whole tour (uint16) in LDS and applies every reversal to it, so the
-// tour needs no exchange; its filter copy covers only its own tile: the column pair arrays for
-// window groups [ilo, ilo+Qw) and plain row arrays for its row band.  Per iteration each
+// tour needs no exchange; its filter copy covers only its own tile: compact column arrays (one float
+// per window position, 4-way interleaved: position w sits in sub-array w & 3 at index w >> 2, so the
+// operands of a lane's two streams -- positions 4 apart -- are two CONSECUTIVE floats, one
+// ds_read2_b32) for window groups [ilo, ilo+Qw), and plain row arrays for its row band.
+// "Shared" geometry (CGeo::sh, CR = 1): every workgroup walks ALL rows and a band of diagonals, so the
+// share of a reversal's touched groups is the same in every workgroup (contiguous row bands are not:
+// a band inside the reversed segment recomputes everything, one outside only a stripe).  Rows and
+// columns then read the SAME arrays, which hold the whole tour once: positions [0, n + 12) with
+// column (and padded row) indices wrapping at n / 4 groups when 4 divides n, else the window
+// extended to the last walked column.  Per iteration each
 // workgroup finds the exact best move of its tile (same filter + exact re-evaluation as above),
 // publishes (delta, index) in a global slot and meets the others at a counter barrier
 // (agent-scope release/acquire, write-through payload: guide G16); all of them then reduce the CS
@@ -23,12 +31,15 @@ struct CGeo {
                             // (stream A the first four, stream B the next four)
     int CS, CR, CD;         // workgroups per tour = CR row bands x CD diagonal-group bands
     int GPw, NSw, MS;       // per workgroup: lane groups, row segments; macro steps per segment
-    int Qw;                 // entries per sub-array of the column pair arrays
+    int Qw;                 // entries per sub-array of the compact column arrays
+    int sh;                 // rows read from the column arrays (CR = 1: whole tour in every workgroup)
+    int wrapg;              // sh: window groups wrap at this index (n / 4), or a huge value (no wrap)
     int rowsw;              // row positions of the band = 4*NSw*MS
     int xlds;
     int K, Ksh;             // macro steps per cache entry ("step group", power of two) and log2(4*K)
     int NG;                 // step groups per unit = ceil(MS / K), <= 64
     int inc;                // group-minimum cache + incremental sweeps (needs GPw*NSw <= nt)
+    int Psh;                // a listed group is recomputed in parts of 2^Psh macro steps (<= K), spread over all lanes
     int lcap;               // capacity of the changed-group list
     float eps2;
 };
@@ -54,15 +65,16 @@ template <typename T>
 struct CView {
     Ctl* ctl;
     uint16_t* tour;
-    v2f *Xq, *Yq, *Eq;      // column pair arrays, slot = u*Qw + local index
-    float *RX, *RY, *RE;    // row band, natural order
-    float* Mc;              // filter minimum of every step group, Mc[group * units + unit], or null
+    float *Xc, *Yc, *Ec;    // compact column arrays, position w (window group ilo + il, w & 3 = u): [u*Qw + il]
+    float *RX, *RY, *RE;    // row band, natural order (null when the rows are read from the column arrays)
+    unsigned* Mc;           // filter minimum of every step group as an ordered key (fkey), Mc[group * units + unit], or null
     uint16_t* list;         // ids (unit * NG + group) of the step groups the last reversal touched
     const T* X;
     double cx, cy, sc;
     int ilo;                // window group of local column index 0
     int rbase;              // tour position (unwrapped) of local row 0
     int rs0, gp0;           // first row segment / lane group of this workgroup
+    int coff;               // column index of this workgroup's first lane group relative to its row (sh: 2*gp0)
 };
 
 template <typename T>
@@ -82,20 +94,15 @@ __device__ void stage_c(const CView<T>& v, const CGeo& g, int tid, int lo, int h
     for (int k = tid; k < 4 * g.Qw; k += g.nt) {
         const int il = k >> 2, u = k & 3, sl = u * g.Qw + il;
         const int w = 4 * (v.ilo + il) + u;
-        const int pa = w % n, pb = (w + 4) % n;
-        if (pa >= lo && pa <= hi) { float x, y; scaled_pos(v, pa, x, y); v.Xq[sl].x = x; v.Yq[sl].x = y; }
-        if (pb >= lo && pb <= hi) { float x, y; scaled_pos(v, pb, x, y); v.Xq[sl].y = x; v.Yq[sl].y = y; }
+        const int pa = w % n;
+        if (pa >= lo && pa <= hi) { float x, y; scaled_pos(v, pa, x, y); v.Xc[sl] = x; v.Yc[sl] = y; }
         if (pa >= elo && pa <= ehi) {
             float x0, y0, x1, y1;
             scaled_pos(v, pa, x0, y0); scaled_pos(v, pa + 1, x1, y1);
-            v.Eq[sl].x = dist32(x0, y0, x1, y1);
-        }
-        if (pb >= elo && pb <= ehi) {
-            float x0, y0, x1, y1;
-            scaled_pos(v, pb, x0, y0); scaled_pos(v, pb + 1, x1, y1);
-            v.Eq[sl].y = dist32(x0, y0, x1, y1);
+            v.Ec[sl] = dist32(x0, y0, x1, y1);
         }
     }
+    if (g.sh) return;
     for (int k = tid; k < g.rowsw + 8; k += g.nt) {
         const int pp = (v.rbase + k) % n;
         if (pp >= lo && pp <= hi) { float x, y; scaled_pos(v, pp, x, y); v.RX[k] = x; v.RY[k] = y; }
@@ -107,25 +114,37 @@ __device__ void stage_c(const CView<T>& v, const CGeo& g, int tid, int lo, int h
     }
 }
 
-__device__ __forceinline__ void load_block_c(const v2f* Xq, const v2f* Yq, const v2f* Eq, int Q, int b,
+__device__ __forceinline__ v2f ld2(const float* p) { return (v2f){p[0], p[1]}; }
+
+// operands of the lane's two streams for column block b: stream A = window positions 4b+2 .. 4b+5 (and
+// edges 4b+1 .. 4b+4), stream B the same 4 positions later = the next float of the same sub-array
+__device__ __forceinline__ void load_block_c(const float* Xc, const float* Yc, const float* Ec, int Q, int b,
                                              v2f (&CX)[4], v2f (&CY)[4], v2f (&E)[4])
 {
-    CX[0] = Xq[2 * Q + b]; CX[1] = Xq[3 * Q + b]; CX[2] = Xq[b + 1]; CX[3] = Xq[Q + b + 1];
-    CY[0] = Yq[2 * Q + b]; CY[1] = Yq[3 * Q + b]; CY[2] = Yq[b + 1]; CY[3] = Yq[Q + b + 1];
-    E[0] = Eq[Q + b]; E[1] = Eq[2 * Q + b]; E[2] = Eq[3 * Q + b]; E[3] = Eq[b + 1];
+    CX[0] = ld2(Xc + 2 * Q + b); CX[1] = ld2(Xc + 3 * Q + b); CX[2] = ld2(Xc + b + 1); CX[3] = ld2(Xc + Q + b + 1);
+    CY[0] = ld2(Yc + 2 * Q + b); CY[1] = ld2(Yc + 3 * Q + b); CY[2] = ld2(Yc + b + 1); CY[3] = ld2(Yc + Q + b + 1);
+    E[0] = ld2(Ec + Q + b); E[1] = ld2(Ec + 2 * Q + b); E[2] = ld2(Ec + 3 * Q + b); E[3] = ld2(Ec + b + 1);
 }
 
-// same macro step as the single-workgroup kernel, rows from the band arrays (rl = local row of r0)
-__device__ __forceinline__ float macro_step_c(const v2f* Xq, const v2f* Yq, const v2f* Eq, int Q,
-                                              const float* RX, const float* RY, const float* RE,
-                                              int rl, int colIdx, const v2f (&CXo)[4],
-                                              const v2f (&CYo)[4], v2f (&CXn)[4], v2f (&CYn)[4],
-                                              const v2f (&Eo)[4], v2f (&En)[4], v2f (&Dc)[4])
+// same macro step as the single-workgroup kernel; rl = local row of r0 (a multiple of 4), colIdx = column
+// block of the NEW operands (already wrapped).  Rows come from the band arrays, or (sh) from the column
+// arrays at row group rl / 4 (wrapped by the caller's rg).
+template <typename T>
+__device__ __forceinline__ float macro_step_c(const CView<T>& v, const CGeo& g, int rl, int rg, int colIdx,
+                                              const v2f (&CXo)[4], const v2f (&CYo)[4], v2f (&CXn)[4],
+                                              v2f (&CYn)[4], const v2f (&Eo)[4], v2f (&En)[4], v2f (&Dc)[4])
 {
-    load_block_c(Xq, Yq, Eq, Q, colIdx, CXn, CYn, En);
+    const int Q = g.Qw;
+    load_block_c(v.Xc, v.Yc, v.Ec, Q, colIdx, CXn, CYn, En);
     float rx[4], ry[4], er[4];
+    if (g.sh) {         // (uniform) positions 4rg+1 .. 4rg+4, edges 4rg .. 4rg+3
+        rx[0] = v.Xc[Q + rg]; rx[1] = v.Xc[2 * Q + rg]; rx[2] = v.Xc[3 * Q + rg]; rx[3] = v.Xc[rg + 1];
+        ry[0] = v.Yc[Q + rg]; ry[1] = v.Yc[2 * Q + rg]; ry[2] = v.Yc[3 * Q + rg]; ry[3] = v.Yc[rg + 1];
+        er[0] = v.Ec[rg]; er[1] = v.Ec[Q + rg]; er[2] = v.Ec[2 * Q + rg]; er[3] = v.Ec[3 * Q + rg];
+    } else {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) { rx[a] = RX[rl + 1 + a]; ry[a] = RY[rl + 1 + a]; er[a] = RE[rl + a]; }
+        for (int a = 0; a < 4; ++a) { rx[a] = v.RX[rl + 1 + a]; ry[a] = v.RY[rl + 1 + a]; er[a] = v.RE[rl + a]; }
+    }
     float mm = INFINITY;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -149,23 +168,35 @@ __device__ __forceinline__ float macro_step_c(const v2f* Xq, const v2f* Yq, cons
 }
 
 // walk `count` consecutive macro steps of one unit starting at local row rl / column index col - 1
-// (Dc rebuilt from scratch); f(mm) receives the filter minimum of every macro step in order
+// (Dc rebuilt from scratch); f(mm) receives the filter minimum of every macro step in order.
+// Shared geometry: row groups and column blocks wrap at g.wrapg (the tour is stored once).
 template <typename T, typename F>
 __device__ __forceinline__ void walk_c(const CView<T>& v, const CGeo& g, int rl, int col, int count, F&& f)
 {
     v2f CX0[4], CY0[4], CX1[4], CY1[4], E0[4], E1[4], Dc[4];
-    load_block_c(v.Xq, v.Yq, v.Eq, g.Qw, col - 1, CX0, CY0, E0);
-    const float ax = v.RX[rl], ay = v.RY[rl];
+    const int wg = g.wrapg;
+    int rg = rl >> 2;
+    rg -= rg >= wg ? wg : 0;
+    int cb = col - 1;
+    cb -= cb >= wg ? wg : 0;
+    load_block_c(v.Xc, v.Yc, v.Ec, g.Qw, cb, CX0, CY0, E0);
+    const float ax = g.sh ? v.Xc[rg] : v.RX[rl], ay = g.sh ? v.Yc[rg] : v.RY[rl];
 #pragma unroll
     for (int q = 0; q < 4; ++q) Dc[q] = dist32x2(ax, ay, CX0[q], CY0[q]);
     int m = 0;
     for (; m + 1 < count; m += 2) {
-        f(macro_step_c(v.Xq, v.Yq, v.Eq, g.Qw, v.RX, v.RY, v.RE, rl, col, CX0, CY0, CX1, CY1, E0, E1, Dc));
-        f(macro_step_c(v.Xq, v.Yq, v.Eq, g.Qw, v.RX, v.RY, v.RE, rl + 4, col + 1, CX1, CY1, CX0, CY0, E1, E0, Dc));
-        rl += 8; col += 2;
+        cb += 1; cb -= cb >= wg ? wg : 0;
+        f(macro_step_c(v, g, rl, rg, cb, CX0, CY0, CX1, CY1, E0, E1, Dc));
+        rg += 1; rg -= rg >= wg ? wg : 0;
+        cb += 1; cb -= cb >= wg ? wg : 0;
+        f(macro_step_c(v, g, rl + 4, rg, cb, CX1, CY1, CX0, CY0, E1, E0, Dc));
+        rg += 1; rg -= rg >= wg ? wg : 0;
+        rl += 8;
     }
-    if (m < count)
-        f(macro_step_c(v.Xq, v.Yq, v.Eq, g.Qw, v.RX, v.RY, v.RE, rl, col, CX0, CY0, CX1, CY1, E0, E1, Dc));
+    if (m < count) {
+        cb += 1; cb -= cb >= wg ? wg : 0;
+        f(macro_step_c(v, g, rl, rg, cb, CX0, CY0, CX1, CY1, E0, E1, Dc));
+    }
 }
 
 // Chunk ids of the cluster kernel: id = unit * NG + group, unit = sl * GPw + gpl (local row segment,
@@ -183,35 +214,38 @@ __device__ __forceinline__ void filter_sweep_c(const CView<T>& v, const CGeo& g,
         const int gpl = u % g.GPw, sl = u / g.GPw;
         if (v.gp0 + gpl >= g.GP) continue;              // padding of the last diagonal band
         unsigned id = (unsigned)u * (unsigned)g.NG;
-        float* mc = v.Mc ? v.Mc + u : nullptr;
+        unsigned* mc = v.Mc ? v.Mc + u : nullptr;
         float gm = INFINITY;
         int k = 0;
         const int K = g.K;
-        walk_c(v, g, 4 * sl * g.MS, sl * g.MS + 2 * gpl + 1, g.MS, [&](float mm) {
+        walk_c(v, g, 4 * sl * g.MS, sl * g.MS + 2 * gpl + 1 + v.coff, g.MS, [&](float mm) {
             gm = __builtin_fminf(gm, mm);
             if (++k == K) {
-                if (mc) { *mc = gm; mc += units; }
+                if (mc) { *mc = fkey(gm); mc += units; }
                 track(gm, id, a1, a2, chunk);
                 gm = INFINITY; k = 0; ++id;
             }
         });
         if (k) {                                        // last, shorter group
-            if (mc) *mc = gm;
+            if (mc) *mc = fkey(gm);
             track(gm, id, a1, a2, chunk);
         }
     }
 }
 
-// filter minimum of one step group, from scratch (incremental sweeps)
+// filter minimum of one part (2^Psh macro steps) of a step group, from scratch (incremental sweeps);
+// +inf for a part beyond the end of the unit
 template <typename T>
-__device__ __forceinline__ float group_min_c(const CView<T>& v, const CGeo& g, int u, int grp)
+__device__ __forceinline__ float part_min_c(const CView<T>& v, const CGeo& g, int u, int grp, int part)
 {
     const int gpl = u % g.GPw, sl = u / g.GPw;
-    const int m0 = grp * g.K;
-    const int cnt = g.MS - m0 < g.K ? g.MS - m0 : g.K;
+    const int P = 1 << g.Psh;
+    const int m0 = grp * g.K + part * P;
+    int cnt = g.MS - m0 < P ? g.MS - m0 : P;
     float gm = INFINITY;
-    walk_c(v, g, 4 * (sl * g.MS + m0), sl * g.MS + 2 * gpl + 1 + m0, cnt,
-           [&](float mm) { gm = __builtin_fminf(gm, mm); });
+    if (cnt > 0)
+        walk_c(v, g, 4 * (sl * g.MS + m0), sl * g.MS + 2 * gpl + 1 + m0 + v.coff, cnt,
+               [&](float mm) { gm = __builtin_fminf(gm, mm); });
     return gm;
 }
 
@@ -255,6 +289,7 @@ __device__ __forceinline__ void sweep_c(const CView<T>& v, const CGeo& g, int ti
                     const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32),
                                                     __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
                     if (pos < (unsigned)g.lcap) v.list[pos] = (uint16_t)(tid * g.NG + q);
+                    v.Mc[q * units + tid] = 0xffffffffu;        // rebuilt below from its parts (atomic min)
                 }
                 base += (unsigned)__popcll(b);
             }
@@ -265,11 +300,17 @@ __device__ __forceinline__ void sweep_c(const CView<T>& v, const CGeo& g, int ti
         if (nl > (unsigned)g.lcap) {
             full = true;                                    // most of the tile moved: plain sweep
         } else {
+            // every listed group is recomputed in parts of 2^Psh macro steps, spread evenly over all lanes:
+            // coarse groups (K up to 64 macro steps) handed out whole leave most lanes waiting for the few
+            // that got one group more
             __builtin_amdgcn_s_setprio(0);
-            for (unsigned t = (unsigned)tid; t < nl; t += (unsigned)g.nt) {
-                const int id = v.list[t];
+            const int psh = __builtin_ctz((unsigned)g.K) - g.Psh;       // log2(parts per group)
+            const unsigned items = nl << psh;
+            for (unsigned t = (unsigned)tid; t < items; t += (unsigned)g.nt) {
+                const int id = v.list[t >> psh];
                 const int u = id / g.NG, q = id - u * g.NG;
-                v.Mc[q * units + u] = group_min_c(v, g, u, q);
+                const float pm = part_min_c(v, g, u, q, (int)(t & ((1u << psh) - 1u)));
+                atomicMin(&v.Mc[q * units + u], fkey(pm));
             }
             __builtin_amdgcn_s_setprio(3);
         }
@@ -282,9 +323,9 @@ __device__ __forceinline__ void sweep_c(const CView<T>& v, const CGeo& g, int ti
             chunk = 0;
             if (own) {
                 unsigned id = (unsigned)tid * (unsigned)g.NG;
-                const float* mc = v.Mc + tid;
+                const unsigned* mc = v.Mc + tid;
                 for (int q = 0; q < g.NG; ++q) {
-                    track(*mc, id, a1, a2, chunk);
+                    track(funkey(*mc), id, a1, a2, chunk);
                     ++id;
                     mc += units;
                 }
@@ -340,7 +381,7 @@ __device__ __forceinline__ void eval_group_c(const CView<T>& v, const CGeo& g, i
         float mm = INFINITY;
         if (lane < g.K && m0 + lane < g.MS) {
             const int gpl = u % g.GPw, sl = u / g.GPw, m = m0 + lane;
-            walk_c(v, g, 4 * (sl * g.MS + m), sl * g.MS + 2 * gpl + 1 + m, 1, [&](float x) { mm = x; });
+            walk_c(v, g, 4 * (sl * g.MS + m), sl * g.MS + 2 * gpl + 1 + m + v.coff, 1, [&](float x) { mm = x; });
         }
         sm = __ballot(mm <= thr);
     }
@@ -424,7 +465,7 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
             const int units = g.GPw * g.NSw, groups = units * g.NG;
             for (int t = tid; t < groups; t += g.nt) {
                 const int q = t / units, u = t - q * units;
-                if (v.Mc[t] <= thr && v.gp0 + u % g.GPw < g.GP) {
+                if (v.Mc[t] <= fkey(thr) && v.gp0 + u % g.GPw < g.GP) {
                     const unsigned pos = atomicAdd(&ctl->nlist, 1u);
                     if (pos < (unsigned)g.lcap) v.list[pos] = (uint16_t)(u * g.NG + q);
                 }
@@ -473,23 +514,27 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
     size_t off = align16(sizeof(Ctl));
     v.tour = reinterpret_cast<uint16_t*>(smem + off);
     off += align16(sizeof(uint16_t) * (size_t)(n + 1));
-    v.Xq = reinterpret_cast<v2f*>(smem + off); off += sizeof(v2f) * 4 * (size_t)g.Qw;
-    v.Yq = reinterpret_cast<v2f*>(smem + off); off += sizeof(v2f) * 4 * (size_t)g.Qw;
-    v.Eq = reinterpret_cast<v2f*>(smem + off); off += sizeof(v2f) * 4 * (size_t)g.Qw;
-    v.RX = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * (size_t)(g.rowsw + 8));
-    v.RY = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * (size_t)(g.rowsw + 8));
-    v.RE = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * (size_t)(g.rowsw + 8));
+    v.Xc = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * 4 * (size_t)g.Qw);
+    v.Yc = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * 4 * (size_t)g.Qw);
+    v.Ec = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * 4 * (size_t)g.Qw);
+    v.RX = v.RY = v.RE = nullptr;
+    if (!g.sh) {
+        v.RX = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * (size_t)(g.rowsw + 8));
+        v.RY = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * (size_t)(g.rowsw + 8));
+        v.RE = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * (size_t)(g.rowsw + 8));
+    }
     v.Mc = nullptr;
     v.list = nullptr;
     if (g.inc) {
         const size_t groups = (size_t)g.GPw * g.NSw * g.NG;
-        v.Mc = reinterpret_cast<float*>(smem + off); off += align16(sizeof(float) * groups);
+        v.Mc = reinterpret_cast<unsigned*>(smem + off); off += align16(sizeof(unsigned) * groups);
         v.list = reinterpret_cast<uint16_t*>(smem + off); off += align16(sizeof(uint16_t) * (size_t)g.lcap);
     }
     T* xl = reinterpret_cast<T*>(smem + off);
     v.rs0 = cr * g.NSw;
     v.gp0 = cd * g.GPw;
-    v.ilo = v.rs0 * g.MS + 2 * v.gp0;
+    v.ilo = g.sh ? 0 : v.rs0 * g.MS + 2 * v.gp0;
+    v.coff = g.sh ? 2 * v.gp0 : 0;
     v.rbase = 4 * v.rs0 * g.MS;
     Ctl* ctl = v.ctl;
     unsigned* cs = p.csync + (size_t)cluster * (size_t)p.cstride;
@@ -614,6 +659,11 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
             for (int k = 0; k < 16; ++k) atomicAdd(&p.stamps[8 + k], pf.fine[k]);
 #endif
         }
+#ifdef TSP2OPT_FINE
+        // the same listed-groups phase (slot 1) and its closing barrier (slot 2) seen by the middle and the last wave
+        if (pf.on && tid == (nt >> 1)) { atomicAdd(&p.stamps[8 + 12], pf.fine[1]); atomicAdd(&p.stamps[8 + 14], pf.fine[2]); }
+        if (pf.on && tid == nt - 64) { atomicAdd(&p.stamps[8 + 13], pf.fine[1]); atomicAdd(&p.stamps[8 + 15], pf.fine[2]); }
+#endif
         if (aborted) {
             // cluster broken (a workgroup is missing): this tour and every later tour of the cluster stay
             // untouched and are flagged, by whichever workgroups got here (same values: idempotent)
