@@ -4,7 +4,7 @@
 # Everything lands in gpurun_out/TAG_*.  Run on the GPU box from the repo root.
 set -u
 TAG=${1:-rXX}; shift || true
-STAGES=${*:-bench kt pmc configs variants phases dist}
+STAGES=${*:-bench kt pmc configs variants phases dist strong}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out
 for st in $STAGES; do
@@ -21,10 +21,13 @@ for st in $STAGES; do
     done ;;
   variants) timeout -k 10 200 python bench.py --mode grouped --no-cpu > $O/${TAG}_bench_tsp500_grouped.json 2>&1 || exit 1
       timeout -k 10 200 python bench.py --dtype f32 --no-cpu > $O/${TAG}_bench_tsp500_f32.json 2>&1 || exit 1 ;;
-  phases) for c in tsp50 tsp100 tsp500 tsp1000; do
+  phases) # the phase timers only exist in the diagnostic build (python -m ml4tspbench_amd.build --fine)
+    for c in tsp50 tsp100 tsp500 tsp1000; do
       echo "   phases $c"
-      timeout -k 10 120 python tools/phase_breakdown.py $c > $O/${TAG}_phase_$c.txt 2>&1 || exit 1
-    done ;;
+      TSP2OPT_LIB=$PWD/ml4tspbench_amd/libtsp2opt_hip_fine.so timeout -k 10 120 python tools/phase_breakdown.py $c > $O/${TAG}_phase_$c.txt 2>&1 || exit 1
+    done
+    TSP2OPT_LIB=$PWD/ml4tspbench_amd/libtsp2opt_hip_fine.so timeout -k 10 200 python tools/phase_breakdown.py tsp10000 f64 1000 > $O/${TAG}_phase_tsp10000.txt 2>&1 || exit 1 ;;
+  strong) timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu --scaling strong > $O/${TAG}_bench_strong1.json 2> $O/${TAG}_bench_strong1.err || exit 1 ;;
   dist) timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu > $O/${TAG}_bench_dist1.json 2> $O/${TAG}_bench_dist1.err || exit 1 ;;
   esac
 done
