@@ -19,8 +19,8 @@ for st in $STAGES; do
       echo "   bench $c"
       timeout -k 10 250 python bench.py --config $c --steps 3 --warmup 1 > $O/${TAG}_bench_$c.json 2> $O/${TAG}_bench_$c.err || exit 1
     done ;;
-  variants) timeout -k 10 200 python bench.py --mode grouped --no-cpu > $O/${TAG}_bench_tsp500_grouped.json 2>&1 || exit 1
-      timeout -k 10 200 python bench.py --dtype f32 --no-cpu > $O/${TAG}_bench_tsp500_f32.json 2>&1 || exit 1 ;;
+  variants) timeout -k 10 200 python bench.py --mode grouped --no-cpu > $O/${TAG}_bench_tsp500_grouped.json 2> $O/${TAG}_bench_tsp500_grouped.err || exit 1
+      timeout -k 10 200 python bench.py --dtype f32 --no-cpu > $O/${TAG}_bench_tsp500_f32.json 2> $O/${TAG}_bench_tsp500_f32.err || exit 1 ;;
   phases) # the phase timers only exist in the diagnostic build (python -m ml4tspbench_amd.build --fine)
     for c in tsp50 tsp100 tsp500 tsp1000; do
       echo "   phases $c"
