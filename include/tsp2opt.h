@@ -166,6 +166,32 @@ int tsp2opt_greedy_decode(const void* heat, const double* points, int64_t* tours
 int64_t tsp2opt_greedy_workspace_bytes(int64_t num_maps, int32_t n, int32_t heat_dtype);
 
 /*
+ * tsp2opt_ls_step -- one call of the reference's other move operators for every tour of a batch:
+ *   op 0: get_two_opt_tour  (search/local_search.py:27-53; cost and reversal as written there: the cost ADDS
+ *         the weight of edge (t[i-1], t[i]), local_search.py:23, and swap() reverses positions i .. j-1)
+ *   op 1: get_relocate_tour (search/local_search.py:75-105 = search/relocate.py:23-38, which tsp_relocate
+ *         applies once per tour, relocate.py:40-61)
+ * The best move -- first strict improvement in the reference's scan order, candidates with
+ * numpy.isclose(0, delta) skipped -- is applied in place; delta_out[k] is its delta (0.0: no move).
+ *   points   (num_instances, n, 2) double (scipy.spatial.distance_matrix of float64 points)
+ *   tours    (num_tours, n+1) int64, updated in place
+ *   fixed_i  (num_tours) int32 or NULL: the operators' fixed_i argument (guided local search)
+ *   guide_k / penalty  (num_tours) double and (num_tours, n, n) double, or both NULL: weights
+ *            dist + guide_k * penalty (edge_weight_guided, search/local_search.py:200)
+ *   status_out (num_tours) int32 or NULL: TSP2OPT_ST_BAD_INDEX (tour untouched) or 0
+ * tsp2opt_local_search -- local_search() (search/local_search.py:125-134): both operators in turn
+ * until a whole round improves nothing; rounds_out[k] counts the rounds, TSP2OPT_ST_CAPPED if max_rounds
+ * stopped it.  All arithmetic is exact double in the reference's operation order: tours are bit-identical.
+ */
+int tsp2opt_ls_step(const double* points, int64_t* tours, double* delta_out, int32_t* status_out,
+                    int64_t num_tours, int32_t n, int32_t tours_per_instance, int32_t op,
+                    const int32_t* fixed_i, const double* guide_k, const double* penalty, int32_t device,
+                    void* hip_stream);
+int tsp2opt_local_search(const double* points, int64_t* tours, int32_t* rounds_out, int32_t* status_out,
+                         int64_t num_tours, int32_t n, int32_t tours_per_instance, int32_t max_rounds,
+                         int32_t device, void* hip_stream);
+
+/*
  * tsp2opt_sqrt_check -- numerics self-test used by the GPU test-suite: out[k] = sqrt(in[k])
  * computed with the exact device routine the delta evaluation uses (dtype as above).  Lets the
  * tests prove 0-ulp agreement with the host's correctly rounded sqrt (SURVEY.md hard part b).

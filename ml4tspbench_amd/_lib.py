@@ -39,6 +39,8 @@ SYMBOLS = (
     "tsp2opt_evaluate",
     "tsp2opt_greedy_decode",
     "tsp2opt_greedy_workspace_bytes",
+    "tsp2opt_ls_step",
+    "tsp2opt_local_search",
     "tsp2opt_sqrt_check",
     "tsp2opt_plan",
     "tsp2opt_debug_greedy_cycles",
@@ -90,6 +92,10 @@ def lib() -> ctypes.CDLL:
     L.tsp2opt_greedy_decode.restype = ctypes.c_int
     L.tsp2opt_greedy_workspace_bytes.argtypes = [i64, i32, i32]
     L.tsp2opt_greedy_workspace_bytes.restype = i64
+    L.tsp2opt_ls_step.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, i32, vp]
+    L.tsp2opt_ls_step.restype = ctypes.c_int
+    L.tsp2opt_local_search.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+    L.tsp2opt_local_search.restype = ctypes.c_int
     L.tsp2opt_sqrt_check.argtypes = [vp, vp, i64, i32, i32, vp]
     L.tsp2opt_sqrt_check.restype = ctypes.c_int
     L.tsp2opt_plan.argtypes = [i32, i32, i32, ctypes.POINTER(i32)]

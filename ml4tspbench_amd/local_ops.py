@@ -1,0 +1,222 @@
+"""Host-side mirror of the reference's other local searches.
+
+Reference interface (read-only):
+  * ``search/relocate.py:40-61``      ``tsp_relocate`` -- one best relocate move per tour
+  * ``search/local_search.py:137-154`` ``tsp_ls``      -- two-opt + relocate until no improvement
+  * ``search/local_search.py:157-232`` ``tsp_gls``     -- (regret) guided local search, wall-clock limited
+  * ``ml4tsp-library/ml4tsp/nar/local_search/guided_ls.py:10-89`` ``ML4TSPNARGuidedLS`` -- the same as a plugin
+registered as ``LOCAL_SEARCH_CLASS[('tsp', 'relocate' | 'ls' | 'gls')]`` (``search/__init__.py:45-52``).
+
+Same names, arguments and return values.  The O(N^2) candidate scans run in ``csrc/ls_ops.hip``
+(``tsp2opt_ls_step`` / ``tsp2opt_local_search``), all tours of a call at once, in exact double arithmetic
+in the reference's operation order, so tours are bit-identical to the reference's for float64 points
+(the reference computes in the dtype ``scipy.spatial.distance_matrix`` returns; float32 points are
+up-cast here).  The guided search keeps its perturbation bookkeeping (edge utilities, penalties, cost
+comparison) on the host exactly like the reference and calls the device operators for the move scans.
+There is no CPU path.
+"""
+from __future__ import annotations
+
+import time
+from typing import Optional, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .local_search import ML4TSPNARLocalSearch
+from .two_opt import _resolve_device
+
+
+def _to_dev(x, dev, dtype):
+    t = x.detach() if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+    return t.to(device=dev, dtype=dtype).contiguous()
+
+
+def _raise_on_status(status: torch.Tensor) -> None:
+    st = status.cpu().numpy()
+    bad = np.nonzero(st & _lib.ST_BAD_INDEX)[0]
+    if len(bad):
+        raise ValueError(f"tour {int(bad[0])} has an index outside [0, N)")
+
+
+def ls_step_device(points: torch.Tensor, tours: torch.Tensor, op: int, *, tours_per_instance: int = 1,
+                   fixed_i: Optional[torch.Tensor] = None, guide_k: Optional[torch.Tensor] = None,
+                   penalty: Optional[torch.Tensor] = None, inplace: bool = False):
+    """One ``get_two_opt_tour`` (op 0) / ``get_relocate_tour`` (op 1) call for every tour, on the device.
+    points (I, N, 2) float64, tours (T, N+1) int64.  Returns ``(tours, delta (T,) float64)``."""
+    if points.dim() == 2:
+        points = points.unsqueeze(0)
+    if tours.dim() == 1:
+        tours = tours.unsqueeze(0)
+    dev = points.device
+    if dev.type != "cuda" or tours.device != dev:
+        raise ValueError("points and tours must live on the same HIP device")
+    n, T = points.shape[1], tours.shape[0]
+    if tours.shape[1] != n + 1 or points.dtype != torch.float64 or tours.dtype != torch.int64:
+        raise ValueError("expected points (I, N, 2) float64 and tours (T, N+1) int64")
+    points = points.contiguous()
+    out = tours.contiguous() if inplace else tours.clone(memory_format=torch.contiguous_format)
+    delta = torch.empty(T, dtype=torch.float64, device=dev)
+    status = torch.zeros(T, dtype=torch.int32, device=dev)
+    fi = None if fixed_i is None else fixed_i.to(device=dev, dtype=torch.int32).contiguous()
+    gk = None if guide_k is None else guide_k.to(device=dev, dtype=torch.float64).contiguous()
+    pen = None if penalty is None else penalty.to(device=dev, dtype=torch.float64).contiguous()
+    if pen is not None and pen.numel() != T * n * n:
+        raise ValueError("penalty must be (T, N, N)")
+    rc = _lib.lib().tsp2opt_ls_step(points.data_ptr(), out.data_ptr(), delta.data_ptr(), status.data_ptr(), T, n,
+                                    int(tours_per_instance), int(op),
+                                    None if fi is None else fi.data_ptr(), None if gk is None else gk.data_ptr(),
+                                    None if pen is None else pen.data_ptr(), dev.index,
+                                    torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "tsp2opt_ls_step")
+    _raise_on_status(status)
+    return out, delta
+
+
+def local_search_device(points: torch.Tensor, tours: torch.Tensor, *, tours_per_instance: int = 1,
+                        max_rounds: int = 1 << 30, inplace: bool = False):
+    """``local_search`` (search/local_search.py:125-134) for every tour.  Returns ``(tours, rounds int32)``."""
+    if points.dim() == 2:
+        points = points.unsqueeze(0)
+    if tours.dim() == 1:
+        tours = tours.unsqueeze(0)
+    dev = points.device
+    if dev.type != "cuda" or tours.device != dev:
+        raise ValueError("points and tours must live on the same HIP device")
+    n, T = points.shape[1], tours.shape[0]
+    if tours.shape[1] != n + 1 or points.dtype != torch.float64 or tours.dtype != torch.int64:
+        raise ValueError("expected points (I, N, 2) float64 and tours (T, N+1) int64")
+    points = points.contiguous()
+    out = tours.contiguous() if inplace else tours.clone(memory_format=torch.contiguous_format)
+    rounds = torch.empty(T, dtype=torch.int32, device=dev)
+    status = torch.zeros(T, dtype=torch.int32, device=dev)
+    rc = _lib.lib().tsp2opt_local_search(points.data_ptr(), out.data_ptr(), rounds.data_ptr(), status.data_ptr(), T,
+                                         n, int(tours_per_instance), int(min(max_rounds, (1 << 31) - 1)), dev.index,
+                                         torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "tsp2opt_local_search")
+    _raise_on_status(status)
+    return out, rounds
+
+
+def tsp_relocate(np_points, tours, adj_mat=None, device="cpu", **kwargs):
+    """Drop-in for ``search/relocate.py:40-61``: the best relocate move of every tour, applied once.
+    Like the reference, ``adj_mat`` only supplies the number of tours (its leading dimension) and tour
+    ``i`` uses ``np_points[i]``; returns a list of tours (lists of N+1 ints)."""
+    dev = _resolve_device(device)
+    t = np.array(tours)
+    if t.ndim == 1:
+        t = t[None]
+    p = np.asarray(np_points)
+    if p.ndim == 2:
+        p = p[None]
+    count = t.shape[0] if adj_mat is None else (1 if np.ndim(adj_mat) == 2 else np.shape(adj_mat)[0])
+    out, _ = ls_step_device(_to_dev(p[:count], dev, torch.float64), _to_dev(t[:count], dev, torch.int64), 1)
+    return [r.tolist() for r in out.cpu().numpy()]
+
+
+def tsp_ls(np_points, tours, adj_mat=None, device="cpu", **kwargs):
+    """Drop-in for ``search/local_search.py:137-154`` (vanilla local search): every tour shares
+    ``np_points`` (N, 2); returns a list of tours.  (The reference's loop over several tours rebinds its
+    own argument and only works for one; here every row of ``tours`` is searched.)"""
+    dev = _resolve_device(device)
+    t = np.array(tours)
+    if t.ndim == 1:
+        t = t[None]
+    out, _ = local_search_device(_to_dev(np.asarray(np_points), dev, torch.float64), _to_dev(t, dev, torch.int64),
+                                 tours_per_instance=t.shape[0])
+    return [r.tolist() for r in out.cpu().numpy()]
+
+
+def _tour_cost(points: np.ndarray, tour: np.ndarray):
+    # TSPEvaluator.evaluate (utils/evaluator.py:9-13): a sequential double sum in tour order
+    d = np.sqrt(np.sum(np.abs(points[tour[1:]] - points[tour[:-1]]) ** 2, axis=-1))
+    total = 0
+    for x in d:
+        total += x
+    return total
+
+
+def _guided_ls_one(points: np.ndarray, tour: np.ndarray, heat: np.ndarray, dev: torch.device, time_limit: float,
+                   perturbation_moves: int, max_rounds: Optional[int]) -> np.ndarray:
+    """search/local_search.py:176-231 for one tour; move scans on the device."""
+    n = points.shape[0]
+    adj = -1 * np.asarray(heat)
+    adj = np.where(adj > 0, adj, 0)
+    d_pts = torch.from_numpy(np.ascontiguousarray(points)).to(dev)
+    init_cost = _tour_cost(points, tour)
+    k = 0.1 * init_cost / n
+    d_k = torch.tensor([k], dtype=torch.float64, device=dev)
+    d_cur, _ = local_search_device(d_pts, torch.from_numpy(tour[None]).to(dev))
+    cur = d_cur[0].cpu().numpy()
+    best, best_cost = cur.copy(), _tour_cost(points, cur)
+    pen = np.zeros((n, n))
+    d_pen = torch.zeros((1, n, n), dtype=torch.float64, device=dev)
+    t_lim = time.time() + time_limit
+    rounds = 0
+    while (time.time() < t_lim) if max_rounds is None else (rounds < max_rounds):
+        moves = 0
+        guard = 0
+        while moves < perturbation_moves:
+            src_a, dst_a = np.minimum(cur[:-1], cur[1:]), np.maximum(cur[:-1], cur[1:])
+            util = adj[src_a, dst_a] / (1 + pen[src_a, dst_a])
+            e = int(np.argmax(util))            # first edge attaining the maximum (local_search.py:189-197)
+            src, dst = int(src_a[e]), int(dst_a[e])
+            pen[src, dst] += 1.
+            pen[dst, src] += 1.
+            d_pen[0, src, dst] += 1.
+            d_pen[0, dst, src] += 1.
+            for node in (src, dst):
+                if node != 0:                   # not the depot
+                    i = int(np.nonzero(cur == node)[0][0])
+                    d_i = torch.tensor([i], dtype=torch.int32, device=dev)
+                    for op in (0, 1):
+                        d_new, delta = ls_step_device(d_pts, d_cur, op, fixed_i=d_i, guide_k=d_k, penalty=d_pen)
+                        if float(delta[0].item()) < 0:
+                            d_cur = d_new
+                            cur = d_cur[0].cpu().numpy()
+                            moves += 1
+            guard += 1
+            if guard > 100000 or (max_rounds is None and time.time() >= t_lim + 10 * max(time_limit, 1.0)):
+                break       # the reference would spin here for ever when no guided move exists
+        d_cur, _ = local_search_device(d_pts, d_cur)
+        cur = d_cur[0].cpu().numpy()
+        cur_cost = _tour_cost(points, cur)
+        if cur_cost < best_cost:
+            best, best_cost = cur.copy(), cur_cost
+        rounds += 1
+    return best
+
+
+def tsp_gls(np_points, tours, adj_mat, device="cpu", **kwargs):
+    """Drop-in for ``search/local_search.py:157-232`` (regret guided local search).  ``kwargs``:
+    ``time_limit`` (seconds, per tour) and ``perturbation_moves`` like the reference; additionally
+    ``max_rounds`` replaces the wall clock by a fixed number of outer rounds (deterministic; tests)."""
+    dev = _resolve_device(device)
+    pts = np.asarray(np_points, dtype=np.float64)
+    adj = np.asarray(adj_mat)
+    t = np.array(tours)
+    if adj.ndim == 2:
+        adj = adj[None]
+        t = t[None] if t.ndim == 1 else t
+    out = []
+    for k in range(adj.shape[0]):
+        out.append(_guided_ls_one(pts, np.asarray(t[k], dtype=np.int64), adj[k], dev, float(kwargs.get("time_limit", 1.0)),
+                                  int(kwargs["perturbation_moves"]), kwargs.get("max_rounds")).tolist())
+    return out
+
+
+class ML4TSPNARGuidedLS(ML4TSPNARLocalSearch):
+    """(Regret) guided local search plugin (ml4tsp/nar/local_search/guided_ls.py:10-89)."""
+
+    def __init__(self, time_limit: float = 1.0, perturbation_moves: int = 50, max_rounds: Optional[int] = None):
+        super().__init__(time_limit=time_limit)
+        self.perturbation_moves = perturbation_moves
+        self.max_rounds = max_rounds
+
+    def _local_search(self, tour: np.ndarray, points: np.ndarray, heatmap: np.ndarray = None) -> np.ndarray:
+        self.nodes_num = points.shape[-2]
+        dev = _resolve_device(self.device)
+        return _guided_ls_one(np.asarray(points, dtype=np.float64), np.asarray(tour, dtype=np.int64),
+                              np.asarray(heatmap), dev, float(self.time_limit), int(self.perturbation_moves),
+                              self.max_rounds)

@@ -60,3 +60,111 @@ def test_oracle_guided_local_search_matches_reference(lso):
             out = lso.guided_local_search(z["points"][k], z["tours_in"][k], z["heat"][k],
                                           rounds=int(z["rounds"]), perturbation_moves=int(z["perturbation_moves"]))
             assert np.array_equal(out, z["tours_out"][k]), (name, k)
+
+
+# ---- GPU: the HIP operators through the C ABI ---------------------------------------------------------
+import torch  # noqa: E402
+
+
+def _dev(x, dtype):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(device="cuda", dtype=dtype)
+
+
+@pytest.mark.gpu
+def test_gpu_relocate_matches_reference():
+    import ml4tspbench_amd as amd
+    for name, z in _load("ls_relocate_*.npz"):
+        n = z["points"].shape[1]
+        out = amd.tsp_relocate(z["points"], z["tours_in"], adj_mat=np.zeros((len(z["tours_in"]), n, n)), device="cuda")
+        assert isinstance(out, list) and isinstance(out[0], list)
+        assert np.array_equal(np.array(out), z["tours_out"]), name
+        f = amd.get_local_search_func("tsp", "relocate")
+        assert np.array_equal(np.array(f(z["points"], z["tours_in"].tolist(), np.zeros((len(z["tours_in"]), n, n)))), z["tours_out"])
+
+
+@pytest.mark.gpu
+def test_gpu_single_operator_calls_match_reference():
+    import ml4tspbench_amd as amd
+    for name, z in _load("ls_step_*.npz"):
+        pts, tin = _dev(z["points"], torch.float64), _dev(z["tours_in"], torch.int64)
+        for op in (0, 1):
+            for g in (0, 1):
+                for f in (0, 1):
+                    out, delta = amd.ls_step_device(
+                        pts, tin, op, fixed_i=_dev(z["fixed_i"], torch.int32) if f else None,
+                        guide_k=_dev(z["guide_k"], torch.float64) if g else None,
+                        penalty=_dev(z["penalty"], torch.float64) if g else None)
+                    key = f"op{op}_g{g}_f{f}"
+                    assert np.array_equal(out.cpu().numpy(), z["out_" + key]), (name, key)
+                    assert np.array_equal(delta.cpu().numpy(), z["delta_" + key]), (name, key)   # bit-exact doubles
+        assert torch.equal(tin.cpu(), torch.from_numpy(z["tours_in"]))                      # input not mutated
+
+
+@pytest.mark.gpu
+def test_gpu_local_search_matches_reference_and_oracle(lso):
+    import ml4tspbench_amd as amd
+    for name, z in _load("ls_loop_*.npz"):
+        for k in range(len(z["tours_in"])):
+            out = amd.tsp_ls(z["points"][k], z["tours_in"][k].tolist(), np.zeros((2, 2)), device="cuda")
+            assert np.array_equal(np.array(out[0]), z["tours_out"][k]), (name, k)
+    rng = np.random.default_rng(12)
+    for n, inst, tpi in ((7, 5, 2), (64, 6, 3), (150, 3, 2), (300, 2, 1)):
+        pts = rng.random((inst, n, 2))
+        tours = np.zeros((inst * tpi, n + 1), dtype=np.int64)
+        for k in range(inst * tpi):
+            tours[k, 1:n] = rng.permutation(np.arange(1, n))
+        ref, ref_rounds = lso.local_search(pts, tours, tours_per_instance=tpi)
+        out, rounds = amd.local_search_device(_dev(pts, torch.float64), _dev(tours, torch.int64), tours_per_instance=tpi)
+        assert np.array_equal(out.cpu().numpy(), ref), n
+        assert np.array_equal(rounds.cpu().numpy(), ref_rounds), n
+        # relocate over long distances (chunked shifts) and both operators on random tours
+        for op in (0, 1):
+            r1, d1 = lso.step(pts, tours, op, tours_per_instance=tpi)
+            o1, e1 = amd.ls_step_device(_dev(pts, torch.float64), _dev(tours, torch.int64), op, tours_per_instance=tpi)
+            assert np.array_equal(o1.cpu().numpy(), r1) and np.array_equal(e1.cpu().numpy(), d1), (n, op)
+
+
+@pytest.mark.gpu
+def test_gpu_long_relocate_shift_both_directions(lso):
+    """A relocate over more than one chunk of 256 positions, towards the front and towards the back."""
+    import ml4tspbench_amd as amd
+    n = 700
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    pts = np.stack([np.cos(ang), np.sin(ang)], axis=1)[None]
+    for src, dst in ((20, 650), (650, 20)):
+        t = np.arange(n + 1, dtype=np.int64)
+        t[-1] = 0
+        node = t[src]
+        body = np.delete(t[:-1], src)
+        body = np.insert(body, dst, node)               # node `src` sits far away from its ring neighbours
+        tour = np.append(body, 0)[None]
+        ref, d = lso.step(pts, tour, 1)
+        assert d[0] < 0 and not np.array_equal(ref, tour)
+        out, e = amd.ls_step_device(_dev(pts, torch.float64), _dev(tour, torch.int64), 1)
+        assert np.array_equal(out.cpu().numpy(), ref) and e.cpu().numpy()[0] == d[0]
+
+
+@pytest.mark.gpu
+def test_gpu_guided_local_search_matches_reference():
+    import ml4tspbench_amd as amd
+    for name, z in _load("ls_gls_*.npz"):
+        for k in range(len(z["tours_in"])):
+            out = amd.tsp_gls(z["points"][k], z["tours_in"][k], z["heat"][k], device="cuda",
+                              time_limit=1.0, perturbation_moves=int(z["perturbation_moves"]),
+                              max_rounds=int(z["rounds"]))
+            assert np.array_equal(np.array(out[0]), z["tours_out"][k]), (name, k)
+    z = _load("ls_gls_n12.npz")[0][1]
+    plug = amd.ML4TSPNARGuidedLS(time_limit=0.05, perturbation_moves=5)
+    res = plug.local_search(z["tours_in"][:2], z["points"][:2], z["heat"][:2])          # wall-clock limited run
+    assert res.shape == (2, 13) and (np.sort(res[:, :-1], axis=1) == np.arange(12)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_ls_rejects_bad_tours():
+    import ml4tspbench_amd as amd
+    pts = np.random.default_rng(0).random((1, 9, 2))
+    t = np.array([[0, 1, 2, 3, 44, 5, 6, 7, 8, 0]])
+    with pytest.raises(ValueError):
+        amd.tsp_relocate(pts, t, adj_mat=np.zeros((1, 9, 9)))
+    with pytest.raises(ValueError):
+        amd.tsp_ls(pts[0], t[0], np.zeros((9, 9)))
