@@ -15,6 +15,7 @@ from .local_search import (  # noqa: F401
 from .local_ops import (  # noqa: F401,E402
     tsp_relocate, tsp_ls, tsp_gls, ML4TSPNARGuidedLS, ls_step_device, local_search_device,
 )
+from .anytime import two_opt_anytime, AnytimeResult  # noqa: F401,E402
 
 # the legacy registry's other local searches (search/__init__.py:45-52)
 LOCAL_SEARCH_CLASS[("tsp", "relocate")] = tsp_relocate
@@ -22,6 +23,7 @@ LOCAL_SEARCH_CLASS[("tsp", "ls")] = tsp_ls
 LOCAL_SEARCH_CLASS[("tsp", "gls")] = tsp_gls
 
 __all__ = [
+    "two_opt_anytime", "AnytimeResult",
     "tsp_relocate", "tsp_ls", "tsp_gls", "ML4TSPNARGuidedLS", "ls_step_device", "local_search_device",
     "batched_two_opt_torch", "tsp_2opt", "two_opt_device", "TwoOptResult", "evaluate_tours", "EvalResult",
     "ML4TSPNARLocalSearch", "ML4TSPNARTwoOpt", "ML4TSPARLocalSearch", "ML4TSPARTwoOpt",

@@ -144,3 +144,32 @@ def test_plugin_validity_rule_on_reference_fixtures():
         else:
             with pytest.raises(ValueError, match="is not valid"):
                 ls._validate(t[None])
+
+
+def test_anytime_checkpoints_follow_the_capped_trajectory(oracle):
+    """two_opt_anytime (docs/gap_time.py:257-327): with iteration slices the lengths after slice s are those
+    of the oracle capped at k (s + 1) iterations, and the final state is the plain run's; with wall-clock
+    slices the lengths never increase and converged tours equal the plain run's."""
+    import ml4tspbench_amd as amd
+    rng = np.random.default_rng(21)
+    inst, tpi, n, k, S = 3, 2, 120, 25, 8
+    pts = rng.random((inst, n, 2))
+    tours = np.zeros((inst * tpi, n + 1), dtype=np.int64)
+    for t in range(inst * tpi):
+        tours[t, 1:n] = rng.permutation(np.arange(1, n))
+    dev = torch.device("cuda", 0)
+    d_p, d_t = torch.from_numpy(pts).to(dev), torch.from_numpy(tours).to(dev)
+    res = amd.two_opt_anytime(d_p, d_t, record_samples=S, slice_iterations=k, tours_per_instance=tpi)
+    for s in range(S):
+        ref, ref_it, _ = oracle.solve(pts, tours, tours_per_instance=tpi, max_iterations=k * (s + 1), threads=4)
+        np.testing.assert_allclose(res.lengths[:, s].cpu().numpy(), oracle.tour_lengths(pts, ref, tpi), rtol=1e-12)
+        assert np.array_equal(res.iterations[:, s].cpu().numpy(), ref_it), s
+    assert np.array_equal(res.tours.cpu().numpy(), ref)
+    assert torch.equal(d_t.cpu(), torch.from_numpy(tours))                      # inputs untouched
+    full, full_it, _ = oracle.solve(pts, tours, tours_per_instance=tpi, threads=4)
+    conv = res.converged.cpu().numpy()
+    assert np.array_equal(conv, full_it <= k * S) or np.array_equal(conv, full_it < k * S)
+    timed = amd.two_opt_anytime(d_p, d_t, record_samples=5, limit_time=2.0, tours_per_instance=tpi)
+    L = timed.lengths.cpu().numpy()
+    assert (np.diff(L, axis=1) <= 1e-12).all() and (np.diff(timed.times.numpy()) > 0).all()
+    assert timed.converged.all() and np.array_equal(timed.tours.cpu().numpy(), full)
