@@ -166,6 +166,35 @@ int tsp2opt_greedy_decode(const void* heat, const double* points, int64_t* tours
 int64_t tsp2opt_greedy_workspace_bytes(int64_t num_maps, int32_t n, int32_t heat_dtype);
 
 /*
+ * tsp2opt_greedy_decode_sparse -- the same decoder for SPARSE heat maps, without densifying them.
+ * Replaces the sparse branch of tsp_greedy (search/greedy_search.py:39-47: two scipy coo matrices turned into
+ * dense N x N arrays and added) + merge_cython for a whole batch:
+ *   values     (num_maps, num_edges) float or double: heat of every listed edge, per heat map
+ *   edge_index (num_instances, 2, num_edges) int64, row-major, num_instances = ceil(num_maps /
+ *              maps_per_instance): edge e of instance q is (ei[q][0][e], ei[q][1][e]); one list per instance
+ *              (the kNN graph of utils/utils.py:168-189, whose length n*k is the same for every instance),
+ *              shared by the maps_per_instance heat maps of that instance; duplicates and both directions of
+ *              a pair are summed like the reference's coo matrices do.  The reference decodes one instance
+ *              per call (num_instances = 1); a batch runs all its instances side by side
+ *   points, tours_out, maps_per_instance: as tsp2opt_greedy_decode
+ * Every node keeps the complete, exactly ordered list of its listed partners (workspace: 24 B per listed
+ * edge and instance + 20 or 28 B per listed edge and heat map, instead of 8 n^2 per heat map); pairs that are not listed
+ * all have the key -0.0 and are taken, after every listed edge, in flat-index order -- the tie rule of the
+ * dense entry point and of the oracle (the reference's order among equal keys is numpy's unstable argsort).
+ * A listed pair whose heat sum is negative (its key would sort after the unlisted pairs) or a node with more
+ * than 8192 listed edges gives TSP2OPT_E_UNSUPPORTED: densify and call tsp2opt_greedy_decode.  n <= 10900.
+ * The call synchronises `hip_stream` (it reads back an error word).  Diagnostics of heat map 0 are left in
+ * the workspace at byte 64 as eight uint64: 10 ns ticks of set-up / listed-edge loop / unlisted pairs /
+ * closing walk, then loop passes, cursor advances, exact tie resolutions, merges made from listed edges.
+ */
+int tsp2opt_greedy_decode_sparse(const void* values, const int64_t* edge_index, const double* points,
+                                 int64_t* tours_out, int64_t num_maps, int32_t n, int64_t num_edges,
+                                 int32_t maps_per_instance, int32_t heat_dtype, int32_t device, void* workspace,
+                                 int64_t workspace_bytes, void* hip_stream);
+int64_t tsp2opt_greedy_sparse_workspace_bytes(int64_t num_maps, int32_t n, int64_t num_edges,
+                                              int32_t maps_per_instance, int32_t heat_dtype);
+
+/*
  * tsp2opt_ls_step -- one call of the reference's other move operators for every tour of a batch:
  *   op 0: get_two_opt_tour  (search/local_search.py:27-53; cost and reversal as written there: the cost ADDS
  *         the weight of edge (t[i-1], t[i]), local_search.py:23, and swap() reverses positions i .. j-1)

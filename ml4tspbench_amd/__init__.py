@@ -7,7 +7,9 @@ host-side mirror of the reference interfaces.
 from .two_opt import (  # noqa: F401
     batched_two_opt_torch, tsp_2opt, two_opt_device, TwoOptResult, evaluate_tours, EvalResult,
 )
-from .greedy import tsp_greedy, greedy_decode_device, get_decoding_func, DECODING_CLASS  # noqa: F401
+from .greedy import (  # noqa: F401
+    tsp_greedy, greedy_decode_device, greedy_decode_sparse_device, get_decoding_func, DECODING_CLASS,
+)
 from .local_search import (  # noqa: F401
     ML4TSPNARLocalSearch, ML4TSPNARTwoOpt, ML4TSPARLocalSearch, ML4TSPARTwoOpt,
     get_local_search_by_name, get_local_search_func, LOCAL_SEARCH_CLASS,
@@ -28,5 +30,5 @@ __all__ = [
     "batched_two_opt_torch", "tsp_2opt", "two_opt_device", "TwoOptResult", "evaluate_tours", "EvalResult",
     "ML4TSPNARLocalSearch", "ML4TSPNARTwoOpt", "ML4TSPARLocalSearch", "ML4TSPARTwoOpt",
     "get_local_search_by_name", "get_local_search_func", "LOCAL_SEARCH_CLASS",
-    "tsp_greedy", "greedy_decode_device", "get_decoding_func", "DECODING_CLASS",
+    "tsp_greedy", "greedy_decode_device", "greedy_decode_sparse_device", "get_decoding_func", "DECODING_CLASS",
 ]

@@ -39,6 +39,8 @@ SYMBOLS = (
     "tsp2opt_evaluate",
     "tsp2opt_greedy_decode",
     "tsp2opt_greedy_workspace_bytes",
+    "tsp2opt_greedy_decode_sparse",
+    "tsp2opt_greedy_sparse_workspace_bytes",
     "tsp2opt_ls_step",
     "tsp2opt_local_search",
     "tsp2opt_sqrt_check",
@@ -96,6 +98,10 @@ def lib() -> ctypes.CDLL:
     L.tsp2opt_ls_step.restype = ctypes.c_int
     L.tsp2opt_local_search.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
     L.tsp2opt_local_search.restype = ctypes.c_int
+    L.tsp2opt_greedy_decode_sparse.argtypes = [vp, vp, vp, vp, i64, i32, i64, i32, i32, i32, vp, i64, vp]
+    L.tsp2opt_greedy_decode_sparse.restype = ctypes.c_int
+    L.tsp2opt_greedy_sparse_workspace_bytes.argtypes = [i64, i32, i64, i32, i32]
+    L.tsp2opt_greedy_sparse_workspace_bytes.restype = i64
     L.tsp2opt_sqrt_check.argtypes = [vp, vp, i64, i32, i32, vp]
     L.tsp2opt_sqrt_check.restype = ctypes.c_int
     L.tsp2opt_plan.argtypes = [i32, i32, i32, ctypes.POINTER(i32)]

@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRCS = [os.path.join(HERE, "csrc", f) for f in ("tsp2opt.hip", "greedy.hip", "ls_ops.hip")]
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("tsp2opt.hip", "greedy.hip", "greedy_sparse.hip", "ls_ops.hip")]
 DEPS = [os.path.join(HERE, "csrc", f) for f in ("wave_reduce.hpp", "host_util.hpp", "two_opt_common.hpp",
                                                  "two_opt_kernel.hpp", "two_opt_band.hpp", "two_opt_aux.hpp")]
 HDR = os.path.join(ROOT, "include", "tsp2opt.h")

@@ -1,0 +1,625 @@
+// ml4tspbench_amd/csrc/greedy_sparse.hip -- greedy edge-merge decoder for SPARSE heat maps
+//
+// Replaces (reference, read-only) the sparse branch of tsp_greedy (search/greedy_search.py:39-47) +
+// merge_cython (search/cython_merge/sources/cython_merge.pyx:19-120): the reference densifies the
+// (values, edge_index) heat map into two N x N arrays, adds them, and argsorts all N^2 keys
+// -S_ij / |v_i - v_j| -- 800 MB of doubles per heat map at N = 10 000 for a k = 50 input.
+//
+// Here the listed edges stay a list.  Structure phase (once per instance, the edge_index is shared by the
+// heat maps of an instance; a call takes one list per instance, all of one length, and works on all of
+// them at once): count / scan / fill build, for every node, the entries (partner, edge id,
+// direction) of every listed edge that touches it, and a rank sort per row orders them by partner so
+// that the two directions (and duplicates) of one pair sit next to each other.  Per heat map: the row's
+// entries are summed per partner in the heat map's dtype exactly like the reference's two coo matrices
+// (S = sum of (i,j) entries + sum of (j,i) entries), keyed in double, and the partners with S > 0 are
+// rank-sorted by exact (key, j): every node's complete candidate list, best first.  The merge loop
+// (one wave per heat map, state in LDS like the dense kernel) then only ever advances cursors: "the
+// best still-valid edge" over the nodes' current candidates is the edge the sorted scan would insert
+// next, and an invalidated candidate is replaced by the next valid entry of the node's list.
+// When no listed edge is valid any more, every remaining pair has S = 0, i.e. the same key -0.0, and
+// the reference's order among them is numpy's unstable argsort (undefined); like the dense path and
+// the oracle, the lower flat index i*n + j wins: the smallest node that is still a fragment end takes
+// its smallest valid partner, until one path is left.  Negative sums (keys that would sort AFTER the
+// zeros) are reported (TSP2OPT_E_UNSUPPORTED) so that the caller can take the dense path.
+//
+// Workspace: 24 B per listed edge and instance for the structure + 20 (fp32 heat) or 28 (fp64) bytes per
+// listed edge and heat map (two entries per edge: partner, fp32 key, sum) instead of 8 N^2.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+
+#include "tsp2opt.h"
+#include "host_util.hpp"
+#include "wave_reduce.hpp"
+
+#pragma clang fp contract(off)
+
+namespace t2o {
+
+constexpr int kSpMaxN = 10900;          // 15 B of LDS state per node
+constexpr int kSpMaxRow = 8192;         // entries of one row the rank sorts accept
+
+// ---- structure phase ---------------------------------------------------------------------------------
+// blockIdx.y = instance in the structure kernels: its edge list ei + inst*2E, its rows at inst*(n+1), its
+// entries at inst*2E
+__global__ void k_sp_count(const int64_t* __restrict__ ei, int64_t E, int n, int* __restrict__ cnt, int* __restrict__ err)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    ei += (size_t)blockIdx.y * 2 * (size_t)E;
+    cnt += (size_t)blockIdx.y * ((size_t)n + 1);
+    const int64_t a = ei[e], b = ei[E + e];
+    if (a < 0 || a >= n || b < 0 || b >= n) { atomicOr(err, 1); return; }
+    if (a == b) return;                                 // the diagonal is never a valid edge
+    atomicAdd(&cnt[a], 1);
+    atomicAdd(&cnt[b], 1);
+}
+
+// exclusive scan of cnt[0..n) into off[0..n], one block; also zeroes the fill cursors and checks the row cap
+__global__ void __launch_bounds__(1024) k_sp_scan(const int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ cur,
+                                                  int n, int cap, int* __restrict__ err)
+{
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    cnt += (size_t)blockIdx.x * ((size_t)n + 1);                        // one block per instance
+    off += (size_t)blockIdx.x * ((size_t)n + 1);
+    if (cur) cur += (size_t)blockIdx.x * ((size_t)n + 1);
+    int s = 0;
+    for (int k = 0; k < per; ++k) {
+        const int i = tid * per + k;
+        if (i < n) {
+            s += cnt[i];
+            if (cap > 0 && cnt[i] > cap) atomicOr(err, 2);
+            if (cap > 0) atomicMax(err + 1, cnt[i]);            // longest row: sizes the key kernel's LDS
+            if (cur) cur[i] = 0;
+        }
+    }
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int k = 0; k < per; ++k) {
+        const int i = tid * per + k;
+        if (i < n) { off[i] = run; run += cnt[i]; }
+    }
+    if (tid == 1023) off[n] = part[1023];
+}
+
+__global__ void k_sp_fill(const int64_t* __restrict__ ei, int64_t E, int n, const int* __restrict__ off, int* __restrict__ cur,
+                          uint16_t* __restrict__ ent_j, int* __restrict__ ent_e)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    ei += (size_t)blockIdx.y * 2 * (size_t)E;
+    off += (size_t)blockIdx.y * ((size_t)n + 1);
+    cur += (size_t)blockIdx.y * ((size_t)n + 1);
+    ent_j += (size_t)blockIdx.y * 2 * (size_t)E;
+    ent_e += (size_t)blockIdx.y * 2 * (size_t)E;
+    const int64_t a = ei[e], b = ei[E + e];
+    if (a < 0 || a >= n || b < 0 || b >= n || a == b) return;
+    int pos = off[a] + atomicAdd(&cur[a], 1);
+    ent_j[pos] = (uint16_t)b;
+    ent_e[pos] = (int)(2 * e);                          // row a holds (a, b): forward, the first coo matrix
+    pos = off[b] + atomicAdd(&cur[b], 1);
+    ent_j[pos] = (uint16_t)a;
+    ent_e[pos] = (int)(2 * e + 1);                      // row b holds the same edge transposed: the second
+}
+
+// one wave per row: entries ordered by (partner, edge id, direction); ucnt[i] = distinct partners
+__global__ void __launch_bounds__(64) k_sp_rowsort(const int* __restrict__ off, const uint16_t* __restrict__ ent_j,
+                                                   const int* __restrict__ ent_e, uint16_t* __restrict__ srt_j,
+                                                   int* __restrict__ srt_e, int* __restrict__ ucnt, int n, int64_t E)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n) return;
+    off += (size_t)blockIdx.y * ((size_t)n + 1);
+    ucnt += (size_t)blockIdx.y * ((size_t)n + 1);
+    ent_j += (size_t)blockIdx.y * 2 * (size_t)E;
+    ent_e += (size_t)blockIdx.y * 2 * (size_t)E;
+    srt_j += (size_t)blockIdx.y * 2 * (size_t)E;
+    srt_e += (size_t)blockIdx.y * 2 * (size_t)E;
+    const int o = off[i], L = off[i + 1] - o;
+    for (int x = lane; x < L; x += 64) {
+        const unsigned long long kx = ((unsigned long long)ent_j[o + x] << 32) | (unsigned)ent_e[o + x];
+        int rank = 0;
+        for (int y = 0; y < L; ++y) {
+            const unsigned long long ky = ((unsigned long long)ent_j[o + y] << 32) | (unsigned)ent_e[o + y];
+            rank += ky < kx ? 1 : 0;
+        }
+        srt_j[o + rank] = (uint16_t)(kx >> 32);
+        srt_e[o + rank] = (int)(unsigned)kx;
+    }
+    __syncthreads();
+    int heads = 0;
+    for (int x = lane; x < L; x += 64) heads += (x == 0 || srt_j[o + x] != srt_j[o + x - 1]) ? 1 : 0;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) heads += __shfl_xor(heads, s);
+    if (lane == 0) ucnt[i] = heads;
+}
+
+// ---- per heat map: sums per partner, keys, candidate lists ---------------------------------------------
+// one wave per (row, heat map).  list_j / list_S [map][uoff[i] + rank]: partners with S > 0 by exact (key, j)
+template <typename H>
+__global__ void __launch_bounds__(64) k_sp_rowkeys(const H* __restrict__ vals, const double* __restrict__ points,
+                                                   const int* __restrict__ off, const uint16_t* __restrict__ srt_j,
+                                                   const int* __restrict__ srt_e, const int* __restrict__ uoff,
+                                                   uint16_t* __restrict__ list_j, float* __restrict__ list_k,
+                                                   H* __restrict__ list_S, int* __restrict__ len, int n, int64_t E, int mpi, int* __restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int64_t m = blockIdx.y;
+    const size_t inst = (size_t)(m / mpi), E2 = 2 * (size_t)E;
+    off += inst * ((size_t)n + 1);
+    uoff += inst * ((size_t)n + 1);
+    srt_j += inst * E2;
+    srt_e += inst * E2;
+    const int o = off[i], L = off[i + 1] - o;
+    double* hk = reinterpret_cast<double*>(smem);                       // keys of the run heads (+inf: dropped)
+    H* hs = reinterpret_cast<H*>(smem + sizeof(double) * (size_t)L);
+    const H* v = vals + (size_t)m * (size_t)E;
+    const double* P = points + inst * (size_t)n * 2;
+    const double xi = P[2 * i], yi = P[2 * i + 1];
+    for (int x = lane; x < L; x += 64) {
+        const int j = srt_j[o + x];
+        double key = INFINITY;
+        H S = (H)0;
+        if (x == 0 || srt_j[o + x - 1] != j) {                          // run head: sum the run
+            H fwd = (H)0, bwd = (H)0;
+            for (int y = x; y < L && srt_j[o + y] == j; ++y) {
+                const int e2 = srt_e[o + y];
+                const H w = v[e2 >> 1];
+                if (e2 & 1) bwd += w; else fwd += w;
+            }
+            S = fwd + bwd;                                              // coo(i,j).toarray() + coo(j,i).toarray()
+            if (S < (H)0 || S != S) atomicOr(err, 4);
+            if (S > (H)0) {
+                const double dx = xi - P[2 * j], dy = yi - P[2 * j + 1];
+                key = -(double)S / sqrt(dx * dx + dy * dy);
+                if (key != key) key = INFINITY;
+            }
+        }
+        hk[x] = key;
+        hs[x] = S;
+    }
+    __syncthreads();
+    int kept = 0;
+    H* outS = list_S + (size_t)m * E2 + uoff[i];
+    uint16_t* outJ = list_j + (size_t)m * E2 + uoff[i];
+    float* outK = list_k + (size_t)m * E2 + uoff[i];
+    for (int x = lane; x < L; x += 64) {
+        const double kx = hk[x];
+        if (kx == INFINITY) continue;
+        const unsigned jx = srt_j[o + x];
+        int rank = 0;
+        for (int y = 0; y < L; ++y) {
+            const double ky = hk[y];
+            if (ky == INFINITY) continue;
+            rank += (ky < kx || (ky == kx && (unsigned)srt_j[o + y] < jx)) ? 1 : 0;
+        }
+        outJ[rank] = (uint16_t)jx;
+        outK[rank] = (float)kx;                                         // what the merge loop compares first
+        outS[rank] = hs[x];
+        ++kept;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) kept += __shfl_xor(kept, s);
+    if (lane == 0) len[(size_t)m * n + i] = kept;
+}
+
+// ---- merge loop ------------------------------------------------------------------------------------------
+// LDS state, 15 B per node: everything a pass needs except the list entries themselves, so that a merge
+// touches no global memory on its critical path and a cursor advance waits for one (coalesced) list read
+struct SpLds {
+    float* key;             // fp32 rounding of the current candidate's key; NaN = none
+    unsigned* pos;          // position of the candidate in this heat map's lists
+    uint16_t* cj;           // the candidate's partner
+    uint16_t* oend;         // other end of the fragment a fragment end belongs to
+    uint16_t* rem;          // entries of the node's list behind the candidate
+    uint8_t* deg;
+};
+
+template <typename H>
+struct SpMap {
+    const uint16_t* lj;     // this heat map's lists
+    const float* lk;
+    const H* lS;
+    const double* P;
+    int n;
+};
+
+template <typename H>
+__device__ __forceinline__ double sp_key(const SpMap<H>& M, int i, int j, H S)
+{
+    const double dx = M.P[2 * i] - M.P[2 * j], dy = M.P[2 * i + 1] - M.P[2 * j + 1];
+    return -(double)S / sqrt(dx * dx + dy * dy);
+}
+
+__device__ __forceinline__ bool sp_ok(const SpLds& L, int i, int oe, int j)
+{
+    return L.deg[j] < 2 && !(j == oe && oe != i);
+}
+
+// node i's candidate is gone: the next valid entry of its list, or none (all lanes)
+template <typename H>
+__device__ __forceinline__ void sp_advance(const SpLds& L, const SpMap<H>& M, int i, int lane)
+{
+    const unsigned p0 = L.pos[i] + 1;
+    const int rem = L.rem[i], oe = L.oend[i];
+    for (int q0 = 0; q0 < rem; q0 += 64) {
+        const int q = q0 + lane;
+        int j = 0;
+        float k = 0.f;
+        bool ok = false;
+        if (q < rem) { j = M.lj[p0 + q]; k = M.lk[p0 + q]; ok = sp_ok(L, i, oe, j); }
+        const unsigned long long bal = __ballot(ok);
+        if (bal) {
+            if (lane == __ffsll((long long)bal) - 1) {
+                L.pos[i] = p0 + (unsigned)q;
+                L.rem[i] = (uint16_t)(rem - q - 1);
+                L.key[i] = k;
+                L.cj[i] = (uint16_t)j;
+            }
+            return;
+        }
+    }
+    if (lane == 0) {
+        L.rem[i] = 0;
+        L.key[i] = __builtin_nanf("");
+    }
+}
+
+__device__ __forceinline__ void sp_refresh_group(const SpLds& L, int n, int x, int lane, float& gm0, float& gm1, float& gm2)
+{
+    const int g = x >> 6, k = (g << 6) + lane;
+    const float v = k < n ? L.key[k] : __builtin_nanf("");
+    const float m = wave_min(v != v ? INFINITY : v);
+    if (lane == (g & 63)) {
+        if (g < 64) gm0 = m;
+        else if (g < 128) gm1 = m;
+        else gm2 = m;
+    }
+}
+
+__device__ __forceinline__ void sp_link(const SpLds& L, uint16_t* nb, int i, int j)
+{
+    const int oi = L.oend[i], oj = L.oend[j];
+    const int di = L.deg[i], dj = L.deg[j];
+    nb[2 * i + di] = (uint16_t)j;               // slot = degree before the merge: no read of the table
+    nb[2 * j + dj] = (uint16_t)i;
+    L.deg[i] = (uint8_t)(di + 1);
+    L.deg[j] = (uint8_t)(dj + 1);
+    if (di >= 1) L.key[i] = __builtin_nanf("");
+    if (dj >= 1) L.key[j] = __builtin_nanf("");
+    L.oend[oi] = (uint16_t)oj;                  // the merged fragment runs from oi to oj
+    L.oend[oj] = (uint16_t)oi;
+}
+
+template <typename H>
+__global__ void __launch_bounds__(64) k_greedy_sparse(const uint16_t* __restrict__ list_j, const float* __restrict__ list_k,
+                                                      const H* __restrict__ list_S,
+                                                      const int* __restrict__ len, const int* __restrict__ uoff,
+                                                      const double* __restrict__ points, uint16_t* __restrict__ nbg,
+                                                      int64_t* __restrict__ tours, int64_t num_maps, int n, int64_t E,
+                                                      int mpi, unsigned long long* __restrict__ dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t b = blockIdx.x;
+    if (b >= num_maps) return;
+    const int lane = threadIdx.x;
+    const int G = (n + 63) >> 6;
+    const size_t inst = (size_t)(b / mpi), E2 = 2 * (size_t)E;
+    uoff += inst * ((size_t)n + 1);
+    const int U = uoff[n];
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long passes = 0, advances = 0, tie_runs = 0;
+    SpLds L;
+    size_t o = 0;
+    L.key = reinterpret_cast<float*>(smem + o); o += sizeof(float) * (size_t)n;
+    L.pos = reinterpret_cast<unsigned*>(smem + o); o += sizeof(unsigned) * (size_t)n;
+    L.cj = reinterpret_cast<uint16_t*>(smem + o); o += sizeof(uint16_t) * (size_t)n;
+    L.oend = reinterpret_cast<uint16_t*>(smem + o); o += sizeof(uint16_t) * (size_t)n;
+    L.rem = reinterpret_cast<uint16_t*>(smem + o); o += sizeof(uint16_t) * (size_t)n;
+    L.deg = reinterpret_cast<uint8_t*>(smem + o);
+    SpMap<H> M{list_j + (size_t)b * E2, list_k + (size_t)b * E2, list_S + (size_t)b * E2,
+               points + inst * (size_t)n * 2, n};
+    const int* lenm = len + (size_t)b * n;
+    uint16_t* nb = nbg + (size_t)b * 2 * (size_t)n;
+    for (int i = lane; i < n; i += 64) {
+        L.oend[i] = (uint16_t)i;
+        L.deg[i] = 0;
+        nb[2 * i] = nb[2 * i + 1] = 0xffffu;
+        const int li = lenm[i];
+        const unsigned base = (unsigned)uoff[i];
+        L.pos[i] = base;
+        L.rem[i] = (uint16_t)(li > 0 ? li - 1 : 0);
+        L.key[i] = li > 0 ? M.lk[base] : __builtin_nanf("");       // first candidates: the heads of the lists
+        L.cj[i] = li > 0 ? M.lj[base] : (uint16_t)0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float gm0 = INFINITY, gm1 = INFINITY, gm2 = INFINITY;
+    for (int g = 0; g < G; ++g) sp_refresh_group(L, n, g << 6, lane, gm0, gm1, gm2);
+    __builtin_amdgcn_wave_barrier();
+
+    int merges = 0;
+    const unsigned long long t1 = wall_clock64();
+    // ---- listed edges: every pass merges or replaces one node's candidate
+    for (long long guard = 0; merges < n - 1 && guard < 4ll * U + 4ll * n + 1024; ++guard) {
+        const float m = wave_min(fminf(fminf(gm0, gm1), gm2));
+        if (!(m < INFINITY)) break;                     // no listed edge is valid any more
+        ++passes;
+        unsigned long long gb0 = __ballot(gm0 == m), gb1 = __ballot(gm1 == m), gb2 = __ballot(gm2 == m);
+        int i = -1, second = -1, hits = 0;
+        unsigned cji = 0, cjs = 0;
+        while (gb0 | gb1 | gb2) {                       // groups whose minimum is m (usually one)
+            int g;
+            if (gb0) { g = __ffsll((long long)gb0) - 1; gb0 &= gb0 - 1; }
+            else if (gb1) { g = 64 + __ffsll((long long)gb1) - 1; gb1 &= gb1 - 1; }
+            else { g = 128 + __ffsll((long long)gb2) - 1; gb2 &= gb2 - 1; }
+            const int k = (g << 6) + lane;
+            const float ck = k < n ? L.key[k] : __builtin_nanf("");
+            const unsigned ccj = k < n ? L.cj[k] : 0u;
+            unsigned long long bal = __ballot(ck == m);
+            hits += __popcll(bal);
+            while (bal && second < 0) {
+                const int src = __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                const unsigned cc = (unsigned)__builtin_amdgcn_readlane((int)ccj, src);
+                if (i < 0) { i = (g << 6) + src; cji = cc; } else { second = (g << 6) + src; cjs = cc; }
+            }
+        }
+        if (hits == 0) break;
+        if (hits > 1 && !(hits == 2 && cji == (unsigned)second && cjs == (unsigned)i)) {
+            // different edges with the same fp32 key: exact keys, recomputed from the listed sums
+            ++tie_runs;
+            double bk = INFINITY;
+            unsigned bf = 0xffffffffu;
+            for (int k = lane; k < n; k += 64) {
+                if (!(L.key[k] == m)) continue;
+                const unsigned cj = L.cj[k];
+                const unsigned f = (unsigned)k * (unsigned)n + cj;
+                const double key = sp_key(M, k, (int)cj, M.lS[L.pos[k]]);
+                if (better(key, f, bk, bf)) { bk = key; bf = f; }
+            }
+            wave_best(bk, bf);
+            i = (int)(bf / (unsigned)n);
+            cji = bf - (unsigned)i * (unsigned)n;
+        }
+        const int j = (int)cji;
+        const bool valid = sp_ok(L, i, L.oend[i], j);
+        if (valid) {
+            if (lane == 0) sp_link(L, nb, i, j);
+            ++merges;
+            __builtin_amdgcn_wave_barrier();
+            // an end that is still open keeps its (now stale or still fine) candidate: it is checked when taken
+            sp_refresh_group(L, n, i, lane, gm0, gm1, gm2);
+            if ((j >> 6) != (i >> 6)) sp_refresh_group(L, n, j, lane, gm0, gm1, gm2);
+        } else {
+            ++advances;
+            sp_advance(L, M, i, lane);
+            __builtin_amdgcn_wave_barrier();
+            sp_refresh_group(L, n, i, lane, gm0, gm1, gm2);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- unlisted pairs: all have the key -0.0, the lower flat index i*n + j goes first: the smallest
+    // fragment end takes its smallest valid partner.  Both only ever move up: i is the smallest open node (it
+    // stays open after its first unlisted merge when it had degree 0), its partner is the smallest open node
+    // above it other than its own far end, so one ascending sweep over the open nodes serves all merges.
+    const unsigned long long t2 = wall_clock64();
+    const int listed_merges = merges;
+    {
+        int i = -1, gi = 0;                             // current smallest open node and the group scan position
+        while (merges < n - 1) {
+            if (i < 0 || L.deg[i] >= 2) {               // (re)locate the smallest open node
+                i = -1;
+                for (; gi < G; ++gi) {
+                    const int k = (gi << 6) + lane;
+                    const unsigned long long bal = __ballot(k < n && L.deg[k] < 2);
+                    if (bal) { i = (gi << 6) + __ffsll((long long)bal) - 1; break; }
+                }
+                if (i < 0) break;
+            }
+            const int oe = L.oend[i];
+            int j = -1;
+            for (int g = i >> 6; g < G; ++g) {
+                const int k = (g << 6) + lane;
+                const unsigned long long bal = __ballot(k < n && L.deg[k] < 2 && k != i && !(k == oe && oe != i));
+                if (bal) { j = (g << 6) + __ffsll((long long)bal) - 1; break; }
+            }
+            if (j < 0) break;                           // cannot happen while two fragments remain
+            if (lane == 0) sp_link(L, nb, i, j);
+            ++merges;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    const unsigned long long t3 = wall_clock64();
+    // closing edge between the two remaining ends, then the walk of greedy_search.py:65-73 over an LDS copy
+    // of the neighbour table
+    int a = -1, c = -1;
+    for (int g = 0; g < G; ++g) {
+        const int k = (g << 6) + lane;
+        unsigned long long bal = __ballot(k < n && L.deg[k] < 2);
+        while (bal) {
+            const int k2 = (g << 6) + __ffsll((long long)bal) - 1;
+            bal &= bal - 1;
+            if (a < 0) a = k2; else c = k2;
+        }
+    }
+    __threadfence_block();
+    unsigned* nbl = L.pos;                              // the cursors are dead by now
+    for (int k = lane; k < n; k += 64) {
+        unsigned lo = nb[2 * k], hi = nb[2 * k + 1];
+        if (a >= 0 && c >= 0) {
+            if (k == a) { if (lo == 0xffffu) lo = (unsigned)c; else hi = (unsigned)c; }
+            if (k == c) { if (lo == 0xffffu) lo = (unsigned)a; else hi = (unsigned)a; }
+        }
+        nbl[k] = lo | (hi << 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (lane == 0) {
+        int64_t* t = tours + (size_t)b * (size_t)(n + 1);
+        int prev = -1, cur = 0;
+        t[0] = 0;
+        for (int k = 1; k <= n; ++k) {
+            const unsigned w = nbl[cur];
+            const int n0 = (int)(w & 0xffffu), n1 = (int)(w >> 16);
+            int best = -1;
+            if (n0 != 0xffff && n0 != prev) best = n0;
+            if (n1 != 0xffff && n1 != prev && n1 > best) best = n1;
+            t[k] = best;
+            prev = cur;
+            cur = best < 0 ? 0 : best;
+        }
+    }
+    if (b == 0 && lane == 0 && dbg) {                   // diagnostics of heat map 0 (10 ns ticks, counts)
+        const unsigned long long t4 = wall_clock64();
+        dbg[0] = t1 - t0; dbg[1] = t2 - t1; dbg[2] = t3 - t2; dbg[3] = t4 - t3;
+        dbg[4] = passes; dbg[5] = advances; dbg[6] = tie_runs; dbg[7] = (unsigned long long)listed_merges;
+    }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------
+struct SpWs {
+    size_t off_err, off_cnt, off_off, off_cur, off_ucnt, off_uoff, off_entj, off_ente, off_srtj, off_srte,
+        off_len, off_nb, off_lj, off_lk, off_lS, total;
+};
+
+SpWs sp_ws(int64_t num_maps, int64_t inst, int n, int64_t E, int hsz)
+{
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    SpWs w{};
+    size_t o = 0;
+    const size_t N1 = ((size_t)n + 1) * (size_t)inst, E2 = 2 * (size_t)E;
+    w.off_err = o; o += 256;
+    w.off_cnt = o; o += up(N1 * 4);
+    w.off_off = o; o += up(N1 * 4);
+    w.off_cur = o; o += up(N1 * 4);
+    w.off_ucnt = o; o += up(N1 * 4);
+    w.off_uoff = o; o += up(N1 * 4);
+    w.off_entj = o; o += up(E2 * inst * 2);
+    w.off_ente = o; o += up(E2 * inst * 4);
+    w.off_srtj = o; o += up(E2 * inst * 2);
+    w.off_srte = o; o += up(E2 * inst * 4);
+    w.off_len = o; o += up((size_t)num_maps * n * 4);
+    w.off_nb = o; o += up((size_t)num_maps * n * 4);
+    w.off_lj = o; o += up((size_t)num_maps * E2 * 2);
+    w.off_lk = o; o += up((size_t)num_maps * E2 * 4);
+    w.off_lS = o; o += up((size_t)num_maps * E2 * (size_t)hsz);
+    w.total = o;
+    return w;
+}
+
+template <typename H>
+int greedy_sparse_t(const void* values, const int64_t* ei, const double* points, int64_t* tours, int64_t num_maps,
+                    int n, int64_t E, int mpi, void* ws, hipStream_t stream)
+{
+    const int64_t inst = (num_maps + mpi - 1) / mpi;
+    const SpWs wl = sp_ws(num_maps, inst, n, E, (int)sizeof(H));
+    unsigned char* w8 = static_cast<unsigned char*>(ws);
+    int* err = reinterpret_cast<int*>(w8 + wl.off_err);
+    int* cnt = reinterpret_cast<int*>(w8 + wl.off_cnt);
+    int* off = reinterpret_cast<int*>(w8 + wl.off_off);
+    int* cur = reinterpret_cast<int*>(w8 + wl.off_cur);
+    int* ucnt = reinterpret_cast<int*>(w8 + wl.off_ucnt);
+    int* uoff = reinterpret_cast<int*>(w8 + wl.off_uoff);
+    uint16_t* entj = reinterpret_cast<uint16_t*>(w8 + wl.off_entj);
+    int* ente = reinterpret_cast<int*>(w8 + wl.off_ente);
+    uint16_t* srtj = reinterpret_cast<uint16_t*>(w8 + wl.off_srtj);
+    int* srte = reinterpret_cast<int*>(w8 + wl.off_srte);
+    int* len = reinterpret_cast<int*>(w8 + wl.off_len);
+    uint16_t* nb = reinterpret_cast<uint16_t*>(w8 + wl.off_nb);
+    uint16_t* lj = reinterpret_cast<uint16_t*>(w8 + wl.off_lj);
+    float* lk = reinterpret_cast<float*>(w8 + wl.off_lk);
+    H* lS = reinterpret_cast<H*>(w8 + wl.off_lS);
+    HIP_TRY(hipMemsetAsync(w8, 0, wl.off_off, stream));                 // err + cnt
+    const unsigned eg = (unsigned)std::max<int64_t>((E + 255) / 256, 1);   // E = 0: one idle block
+    const unsigned ig = (unsigned)inst;
+    hipLaunchKernelGGL(k_sp_count, dim3(eg, ig), dim3(256), 0, stream, ei, E, n, cnt, err);
+    hipLaunchKernelGGL(k_sp_scan, dim3(ig), dim3(1024), 0, stream, cnt, off, cur, n, kSpMaxRow, err);
+    hipLaunchKernelGGL(k_sp_fill, dim3(eg, ig), dim3(256), 0, stream, ei, E, n, off, cur, entj, ente);
+    hipLaunchKernelGGL(k_sp_rowsort, dim3((unsigned)n, ig), dim3(64), 0, stream, off, entj, ente, srtj, srte, ucnt, n, E);
+    hipLaunchKernelGGL(k_sp_scan, dim3(ig), dim3(1024), 0, stream, ucnt, uoff, (int*)nullptr, n, 0, err);
+    HIP_TRY(hipGetLastError());
+    // a row's keys and sums are staged in LDS: rows are capped at kSpMaxRow entries (checked on the device)
+    const size_t rlds = (size_t)kSpMaxRow * (sizeof(double) + sizeof(H));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_rowkeys<H>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+    int eh[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(eh, err, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    int errh = eh[0];
+    if (errh & 1) return fail(TSP2OPT_E_ARG, "edge_index has an entry outside [0, n)");
+    if (errh & 2) return fail(TSP2OPT_E_UNSUPPORTED, "a node has more than 8192 listed edges: use the dense decoder");
+    // the longest row bounds the LDS request of the key kernel (one wave per row: short rows, many per CU)
+    const size_t klds = ((size_t)std::max(eh[1], 1) * (sizeof(double) + sizeof(H)) + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(k_sp_rowkeys<H>, dim3((unsigned)n, (unsigned)num_maps), dim3(64), klds, stream,
+                       static_cast<const H*>(values), points, off, srtj, srte, uoff, lj, lk, lS, len, n, E, mpi, err);
+    HIP_TRY(hipGetLastError());
+    const size_t lds = (size_t)n * 15 + 64;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_sparse<H>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_greedy_sparse<H>, dim3((unsigned)num_maps), dim3(64), lds, stream, lj, lk, lS, len, uoff, points,
+                       nb, tours, num_maps, n, E, mpi, reinterpret_cast<unsigned long long*>(err + 16));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&errh, err, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (errh & 4)
+        return fail(TSP2OPT_E_UNSUPPORTED, "a listed pair has a negative (or NaN) heat sum: its key sorts after the "
+                                           "unlisted pairs; use the dense decoder");
+    return 0;
+}
+
+}  // namespace t2o
+
+using namespace t2o;
+
+extern "C" int64_t tsp2opt_greedy_sparse_workspace_bytes(int64_t num_maps, int32_t n, int64_t num_edges,
+                                                         int32_t maps_per_instance, int32_t heat_dtype)
+{
+    if (num_maps < 0 || n < 2 || num_edges < 0 || maps_per_instance < 1) return fail(TSP2OPT_E_ARG, "bad size");
+    if (heat_dtype != TSP2OPT_DTYPE_F32 && heat_dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
+    const int64_t inst = (num_maps + maps_per_instance - 1) / maps_per_instance;
+    return (int64_t)sp_ws(num_maps, inst, n, num_edges, heat_dtype == TSP2OPT_DTYPE_F64 ? 8 : 4).total;
+}
+
+extern "C" int tsp2opt_greedy_decode_sparse(const void* values, const int64_t* edge_index, const double* points,
+                                            int64_t* tours_out, int64_t num_maps, int32_t n, int64_t num_edges,
+                                            int32_t maps_per_instance, int32_t heat_dtype, int32_t device,
+                                            void* workspace, int64_t workspace_bytes, void* hip_stream)
+{
+    if (num_maps < 0 || n < 2 || maps_per_instance < 1 || num_edges < 0) return fail(TSP2OPT_E_ARG, "bad size");
+    if (n > kSpMaxN) return fail(TSP2OPT_E_UNSUPPORTED, "sparse greedy decode supports n <= 10900");
+    if (num_edges > 0x3fffffffll) return fail(TSP2OPT_E_UNSUPPORTED, "too many edges");
+    if (num_maps > 65535) return fail(TSP2OPT_E_UNSUPPORTED, "more than 65535 heat maps per call");
+    if (num_edges * ((num_maps + maps_per_instance - 1) / maps_per_instance) > 0x3fffffffll)
+        return fail(TSP2OPT_E_UNSUPPORTED, "too many edges in one call");
+    if (heat_dtype != TSP2OPT_DTYPE_F32 && heat_dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
+    if (num_maps == 0) return 0;
+    if (!points || !tours_out || !workspace || (num_edges > 0 && (!values || !edge_index)))
+        return fail(TSP2OPT_E_ARG, "null pointer");
+    if (workspace_bytes < tsp2opt_greedy_sparse_workspace_bytes(num_maps, n, num_edges, maps_per_instance, heat_dtype))
+        return fail(TSP2OPT_E_WORKSPACE, "workspace too small");
+    if ((reinterpret_cast<uintptr_t>(values) % (heat_dtype == TSP2OPT_DTYPE_F64 ? 8 : 4)) ||
+        (reinterpret_cast<uintptr_t>(points) % 8) || (reinterpret_cast<uintptr_t>(tours_out) % 8) ||
+        (reinterpret_cast<uintptr_t>(edge_index) % 8))
+        return fail(TSP2OPT_E_ARG, "misaligned pointer (arrays must be aligned to their element size)");
+    if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(TSP2OPT_E_ARG, "workspace must be 256-byte aligned");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(TSP2OPT_E_HIP, "hipSetDevice failed");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (heat_dtype == TSP2OPT_DTYPE_F64)
+        return greedy_sparse_t<double>(values, edge_index, points, tours_out, num_maps, n, num_edges,
+                                       maps_per_instance, workspace, stream);
+    return greedy_sparse_t<float>(values, edge_index, points, tours_out, num_maps, n, num_edges, maps_per_instance,
+                                  workspace, stream);
+}

@@ -47,6 +47,49 @@ def greedy_decode_device(heat: torch.Tensor, points: torch.Tensor, *, maps_per_i
     return tours
 
 
+def greedy_decode_sparse_device(values: torch.Tensor, edge_index: torch.Tensor, points: torch.Tensor, *,
+                                maps_per_instance: int = 1, return_diagnostics: bool = False):
+    """Sparse heat maps without densifying them: values (B, E) float32/float64, edge_index (I, 2, E) integer
+    (one list per instance, shared by its maps_per_instance heat maps; (2, E) for a single instance),
+    points (I, N, 2), all on one HIP device, B == I * maps_per_instance.
+    Returns tours (B, N+1) int64 on the device.  Raises ``Tsp2optError`` (code -2) for inputs the sparse
+    kernels do not take (negative heat sums, a node with more than 8192 listed edges): densify then."""
+    if values.device.type != "cuda" or points.device != values.device:
+        raise ValueError("values and points must live on the same HIP device")
+    if points.dim() == 2:
+        points = points.unsqueeze(0)
+    if values.dim() == 1:
+        values = values.unsqueeze(0)
+    if edge_index.dim() == 2:
+        edge_index = edge_index.unsqueeze(0)
+    B, E = values.shape
+    I, n = points.shape[0], points.shape[1]
+    if tuple(edge_index.shape) != (I, 2, E) or B != I * maps_per_instance:
+        raise ValueError("expected values (I * maps_per_instance, E), edge_index (I, 2, E) and points (I, N, 2)")
+    if values.dtype not in (torch.float32, torch.float64):
+        values = values.to(torch.float32)
+    values = values.contiguous()
+    ei = edge_index.to(device=values.device, dtype=torch.int64).contiguous()
+    pts = points.to(torch.float64).contiguous()
+    dev = values.device
+    code = _lib.DTYPE_F64 if values.dtype == torch.float64 else _lib.DTYPE_F32
+    L = _lib.lib()
+    need = L.tsp2opt_greedy_sparse_workspace_bytes(B, n, E, int(maps_per_instance), code)
+    _lib.check(need, "tsp2opt_greedy_sparse_workspace_bytes")
+    ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+    tours = torch.empty((B, n + 1), dtype=torch.int64, device=dev)
+    rc = L.tsp2opt_greedy_decode_sparse(values.data_ptr(), ei.data_ptr(), pts.data_ptr(), tours.data_ptr(), B, n, E,
+                                        int(maps_per_instance), code, dev.index, ws.data_ptr(), ws.numel(),
+                                        torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "tsp2opt_greedy_decode_sparse")
+    if return_diagnostics:
+        d = ws[64:128].cpu().numpy().view("uint64")
+        names = ("setup_ticks", "listed_ticks", "unlisted_ticks", "walk_ticks", "passes", "advances", "tie_runs",
+                 "listed_merges")
+        return tours, {k: int(v) for k, v in zip(names, d)}
+    return tours
+
+
 def tsp_greedy(adj_mat, np_points, edge_index_np=None, sparse_graph=False, parallel_sampling=1,
                device="cpu", **kwargs):
     """Drop-in for ``search/greedy_search.py:19-74``.
@@ -68,6 +111,12 @@ def tsp_greedy(adj_mat, np_points, edge_index_np=None, sparse_graph=False, paral
             raise AssertionError("edge_index_np must be given when graph is sparse")
         ei = torch.as_tensor(np.asarray(edge_index_np)).to(dev).long()
         vals = a.reshape(parallel_sampling, -1)
+        try:        # the listed edges stay a list (no N x N arrays); inputs it does not take are densified below
+            tours = greedy_decode_sparse_device(vals, ei, pts.to(dev)[None], maps_per_instance=parallel_sampling)
+            return [t.tolist() for t in tours.cpu().numpy()]
+        except _lib.Tsp2optError as exc:
+            if "(-2)" not in str(exc):
+                raise
         heat = torch.zeros((parallel_sampling, n, n), dtype=vals.dtype, device=dev)
         heat.index_put_((torch.arange(parallel_sampling, device=dev)[:, None].expand(-1, ei.shape[1]),
                          ei[0][None].expand(parallel_sampling, -1), ei[1][None].expand(parallel_sampling, -1)),

@@ -127,3 +127,132 @@ def test_gpu_greedy_grid_of_n(kind):
                 if not np.array_equal(got[m], greedy_oracle.greedy(pts[m // 2], heat[m])[0]):
                     bad.append((n, dtype.__name__, m))
     assert not bad, bad
+
+
+# ---- sparse heat maps: (values, edge_index) without densifying ----------------------------------------
+def _knn_inputs(rng, n, k, maps, dtype, self_loops=True, dup=0):
+    """kNN graph like utils/utils.py:168-189 (source-major, the node itself among its neighbours) with
+    positive heat values; `dup` extra duplicated edges."""
+    pts = rng.random((n, 2))
+    d = ((pts[:, None] - pts[None]) ** 2).sum(-1)
+    nn = np.argsort(d, axis=1)[:, :k] if self_loops else np.argsort(d, axis=1)[:, 1:k + 1]
+    e0 = np.repeat(np.arange(n), nn.shape[1])
+    e1 = nn.reshape(-1)
+    if dup:
+        pick = rng.integers(0, len(e0), size=dup)
+        e0, e1 = np.concatenate([e0, e0[pick]]), np.concatenate([e1, e1[pick]])
+    ei = np.stack([e0, e1]).astype(np.int64)
+    vals = (rng.random((maps, ei.shape[1])) + 0.01).astype(dtype)
+    return pts, ei, vals
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k,maps,dtype,dup", [(12, 4, 3, np.float32, 0), (60, 6, 2, np.float64, 5),
+                                                (200, 10, 3, np.float32, 0), (1000, 50, 2, np.float32, 40),
+                                                (3000, 20, 1, np.float32, 0), (700, 3, 2, np.float32, 0)])
+def test_gpu_sparse_greedy_matches_oracle_and_dense_path(n, k, maps, dtype, dup):
+    """The sparse decoder against the CPU oracle on the densified heat map (the oracle's and the dense
+    kernel's tie rule -- lower flat index -- is also the sparse path's rule for the unlisted, all-equal
+    pairs, so the tours must be identical, ties included) and against the dense HIP decoder."""
+    from ml4tspbench_amd import greedy_decode_device, greedy_decode_sparse_device
+    from oracle import greedy_oracle
+    rng = np.random.default_rng(700 + n + k)
+    pts, ei, vals = _knn_inputs(rng, n, k, maps, dtype, dup=dup)
+    dev = torch.device("cuda", 0)
+    got = greedy_decode_sparse_device(torch.from_numpy(vals).to(dev), torch.from_numpy(ei).to(dev),
+                                      torch.from_numpy(pts).to(dev)[None], maps_per_instance=maps).cpu().numpy()
+    dense = greedy_oracle.densify(vals, ei, n)
+    ref = greedy_oracle.greedy(pts, dense)
+    assert np.array_equal(got, ref)
+    d_got = greedy_decode_device(torch.from_numpy(dense).to(dev), torch.from_numpy(pts).to(dev)[None],
+                                 maps_per_instance=maps).cpu().numpy()
+    assert np.array_equal(d_got, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gpu_sparse_greedy_batch_of_instances(dtype):
+    """One call, one edge list per instance (equal lengths), maps_per_instance heat maps each: every map equals
+    the single-instance call and the oracle."""
+    from ml4tspbench_amd import greedy_decode_sparse_device
+    from oracle import greedy_oracle
+    rng = np.random.default_rng(91)
+    inst, n, k, maps = 5, 130, 7, 3
+    data = [_knn_inputs(rng, n, k, maps, dtype, dup=4) for _ in range(inst)]
+    dev = torch.device("cuda", 0)
+    pts = torch.from_numpy(np.stack([d[0] for d in data])).to(dev)
+    ei = torch.from_numpy(np.stack([d[1] for d in data])).to(dev)
+    vals = torch.from_numpy(np.concatenate([d[2] for d in data])).to(dev)
+    got, diag = greedy_decode_sparse_device(vals, ei, pts, maps_per_instance=maps, return_diagnostics=True)
+    got = got.cpu().numpy()
+    assert diag["passes"] > 0 and diag["listed_merges"] <= n - 1
+    for q, (p, e, v) in enumerate(data):
+        ref = greedy_oracle.greedy(p, greedy_oracle.densify(v, e, n))
+        assert np.array_equal(got[q * maps:(q + 1) * maps], ref), q
+    with pytest.raises(ValueError):
+        greedy_decode_sparse_device(vals, ei[:2], pts, maps_per_instance=maps)
+
+
+@pytest.mark.gpu
+def test_gpu_sparse_greedy_front_end_and_fallbacks():
+    from ml4tspbench_amd import tsp_greedy, greedy_decode_sparse_device, _lib
+    from oracle import greedy_oracle
+    rng = np.random.default_rng(3)
+    pts, ei, vals = _knn_inputs(rng, 150, 8, 2, np.float32)
+    tours = tsp_greedy(vals.reshape(-1), pts, edge_index_np=ei, sparse_graph=True, parallel_sampling=2)
+    ref = greedy_oracle.greedy(pts, greedy_oracle.densify(vals, ei, 150))
+    assert isinstance(tours, list) and np.array_equal(np.array(tours), ref)
+    # a negative heat sum sorts after the unlisted pairs: the sparse kernels refuse, the front end densifies
+    neg = vals.copy()
+    neg[:, 5] = -5.0                                   # the reverse listing (<= 1.01) cannot lift the sum above 0
+    dev = torch.device("cuda", 0)
+    with pytest.raises(_lib.Tsp2optError):
+        greedy_decode_sparse_device(torch.from_numpy(neg).to(dev), torch.from_numpy(ei).to(dev),
+                                    torch.from_numpy(pts).to(dev)[None], maps_per_instance=2)
+    tours = tsp_greedy(neg.reshape(-1), pts, edge_index_np=ei, sparse_graph=True, parallel_sampling=2)
+    assert np.array_equal(np.array(tours), greedy_oracle.greedy(pts, greedy_oracle.densify(neg, ei, 150)))
+    bad = ei.copy()
+    bad[1, 7] = 150
+    with pytest.raises(_lib.Tsp2optError):
+        greedy_decode_sparse_device(torch.from_numpy(vals).to(dev), torch.from_numpy(bad).to(dev),
+                                    torch.from_numpy(pts).to(dev)[None], maps_per_instance=2)
+    # no listed edge at all: every pair ties, flat-index order builds the path 0-1-2-...
+    empty = greedy_decode_sparse_device(torch.zeros((1, 0), dtype=torch.float32, device=dev),
+                                        torch.zeros((2, 0), dtype=torch.int64, device=dev),
+                                        torch.from_numpy(pts[:9]).to(dev)[None]).cpu().numpy()
+    assert np.array_equal(empty, greedy_oracle.greedy(pts[:9], np.zeros((1, 9, 9), dtype=np.float32)))
+
+
+@pytest.mark.gpu
+def test_gpu_sparse_greedy_tsp10000_k50_full_size():
+    """BASELINE.json configs[3]/[4] scale: 16 heat maps of 10 000 nodes with k = 50 listed neighbours stay a
+    list (the dense decoder would need 12.8 GB of key matrices): valid tours that 2-opt improves, the workspace
+    stays under 400 MB, and two of the maps are checked against the dense HIP decoder."""
+    from ml4tspbench_amd import greedy_decode_device, greedy_decode_sparse_device, two_opt_device, evaluate_tours, _lib
+    n, k, maps = 10000, 50, 16
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    pts = torch.rand((maps, n, 2), generator=g, device=dev, dtype=torch.float64)
+    vals_all, ei_all = [], []
+    for m in range(maps):
+        d = torch.cdist(pts[m], pts[m])
+        dk, nn = d.topk(k, dim=1, largest=False)
+        ei_all.append(torch.stack([torch.arange(n, device=dev).repeat_interleave(k), nn.reshape(-1)]))
+        vals_all.append((torch.exp(-dk / (0.35 / n ** 0.5)) * (0.6 + 0.8 * torch.rand(dk.shape, generator=g, device=dev,
+                                                                                   dtype=torch.float64))).float().reshape(1, -1))
+        del d
+    tours = greedy_decode_sparse_device(torch.cat(vals_all), torch.stack(ei_all), pts)      # 16 instances, one call
+    need = _lib.lib().tsp2opt_greedy_sparse_workspace_bytes(maps, n, n * k, 1, _lib.DTYPE_F32)
+    assert need < 400 * 2 ** 20, need                   # 44 B per listed edge (24 structure + 20 lists) vs 12.8 GB
+    ev0 = evaluate_tours(pts, tours)
+    assert ((ev0.valid.cpu().numpy() & 7) == 7).all()
+    res = two_opt_device(pts, tours, max_iterations=300)
+    ev = evaluate_tours(pts, res.tours)
+    assert ((ev.valid.cpu().numpy() & 7) == 7).all() and (ev.lengths < ev0.lengths).all()
+    for m in (0, 9):                                     # dense path on the densified map: same tour
+        heat = torch.zeros((1, n, n), dtype=torch.float32, device=dev)
+        heat[0].index_put_((ei_all[m][0], ei_all[m][1]), vals_all[m][0], accumulate=True)
+        dense = greedy_decode_device(heat, pts[m][None])
+        assert torch.equal(dense[0], tours[m]), m
+        del heat

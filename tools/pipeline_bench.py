@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--config", default="tsp100", choices=sorted(CONFIGS))
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--knn", type=int, default=0)
+    ap.add_argument("--sparse", action="store_true",
+                    help="with --knn: also decode from (values, edge_index) lists (one list per instance, one call "
+                         "for the batch) and use those tours downstream")
     ap.add_argument("--check", type=int, default=2, help="instances checked against the CPU oracles")
     ap.add_argument("--max-iterations", type=int, default=5000)
     ap.add_argument("--cluster-mode", type=int, default=-1, help="diagnostic, see bench.py")
@@ -66,12 +69,27 @@ def main():
     pts_np = rng.random((inst, n, 2))
     pts = torch.from_numpy(pts_np).to(dev)
     heat = make_heat(pts, per, args.knn, 1234)
+    lists = None
+    if args.sparse:
+        if not args.knn:
+            raise SystemExit("--sparse needs --knn")
+        lists = []
+        for k in range(inst):                   # the list form of the same heat maps: listed = nonzero in map 0
+            ei = (heat[k * per] != 0).nonzero().T.contiguous()
+            lists.append((torch.stack([heat[k * per + m][ei[0], ei[1]] for m in range(per)]).contiguous(), ei))
+        if len({int(ei.shape[1]) for _, ei in lists}) != 1:
+            raise SystemExit("instances list different numbers of edges")
+        sp_vals = torch.cat([v for v, _ in lists]).contiguous()          # (inst*per, E)
+        sp_ei = torch.stack([ei for _, ei in lists]).contiguous()        # (inst, 2, E)
     torch.cuda.synchronize()
 
     def run():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-        tours = amd.greedy_decode_device(heat, pts, maps_per_instance=per)
+        if lists is None:
+            tours = amd.greedy_decode_device(heat, pts, maps_per_instance=per)
+        else:
+            tours = amd.greedy_decode_sparse_device(sp_vals, sp_ei, pts, maps_per_instance=per)
         ev[1].record()
         res = amd.two_opt_device(pts, tours, tours_per_instance=per, group_size=1,
                                  max_iterations=args.max_iterations, want_lengths=False)
@@ -104,6 +122,19 @@ def main():
         "mean_length_after_2opt": float(sel.lengths.mean().item()),
         "mean_length_best_of_p": float(sel.best_length.mean().item()),
     }
+    if lists is not None:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        dense_tours = amd.greedy_decode_device(heat, pts, maps_per_instance=per)
+        ev[1].record()
+        torch.cuda.synchronize()
+        _, diag = amd.greedy_decode_sparse_device(sp_vals, sp_ei, pts, maps_per_instance=per, return_diagnostics=True)
+        out["sparse"] = {"map0_diagnostics": diag, "listed_edges_per_instance": int(lists[0][1].shape[1]),
+                         "workspace_bytes": int(_lib.lib().tsp2opt_greedy_sparse_workspace_bytes(
+                             inst * per, n, int(lists[0][1].shape[1]), per, _lib.DTYPE_F32)),
+                         "dense_decode_ms": float(ev[0].elapsed_time(ev[1])),
+                         "dense_key_bytes": int(inst * per * n * n * 8),
+                         "same_tours_as_dense_decode": bool(torch.equal(dense_tours, tours))}
     if args.phases:
         from ml4tspbench_amd import two_opt
         L = _lib.lib()
