@@ -177,7 +177,7 @@ int64_t tsp2opt_greedy_workspace_bytes(int64_t num_maps, int32_t n, int32_t heat
  *              a pair are summed like the reference's coo matrices do.  The reference decodes one instance
  *              per call (num_instances = 1); a batch runs all its instances side by side
  *   points, tours_out, maps_per_instance: as tsp2opt_greedy_decode
- * Every node keeps the complete, exactly ordered list of its listed partners (workspace: 24 B per listed
+ * Every node keeps the complete, exactly ordered list of its listed partners (workspace: 28 B per listed
  * edge and instance + 20 or 28 B per listed edge and heat map, instead of 8 n^2 per heat map); pairs that are not listed
  * all have the key -0.0 and are taken, after every listed edge, in flat-index order -- the tie rule of the
  * dense entry point and of the oracle (the reference's order among equal keys is numpy's unstable argsort).
@@ -185,7 +185,8 @@ int64_t tsp2opt_greedy_workspace_bytes(int64_t num_maps, int32_t n, int32_t heat
  * than 8192 listed edges gives TSP2OPT_E_UNSUPPORTED: densify and call tsp2opt_greedy_decode.  n <= 10900.
  * The call synchronises `hip_stream` (it reads back an error word).  Diagnostics of heat map 0 are left in
  * the workspace at byte 64 as eight uint64: 10 ns ticks of set-up / listed-edge loop / unlisted pairs /
- * closing walk, then loop passes, cursor advances, exact tie resolutions, merges made from listed edges.
+ * closing walk, then rounds, rounds that fell back to one exactly compared edge, 0, merges made from listed
+ * edges.
  */
 int tsp2opt_greedy_decode_sparse(const void* values, const int64_t* edge_index, const double* points,
                                  int64_t* tours_out, int64_t num_maps, int32_t n, int64_t num_edges,

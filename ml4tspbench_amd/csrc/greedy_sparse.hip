@@ -13,16 +13,17 @@
 // entries are summed per partner in the heat map's dtype exactly like the reference's two coo matrices
 // (S = sum of (i,j) entries + sum of (j,i) entries), keyed in double, and the partners with S > 0 are
 // rank-sorted by exact (key, j): every node's complete candidate list, best first.  The merge loop
-// (one wave per heat map, state in LDS like the dense kernel) then only ever advances cursors: "the
-// best still-valid edge" over the nodes' current candidates is the edge the sorted scan would insert
-// next, and an invalidated candidate is replaced by the next valid entry of the node's list.
+// (one workgroup per heat map, 15 B of LDS state per node) then only ever advances cursors: "the best
+// still-valid edge" over the nodes' current candidates is the edge the sorted scan would insert next, an
+// invalidated candidate is replaced by the next valid entry of the node's list, and edges whose turn nothing
+// can disturb are inserted many per round (see k_greedy_sparse).
 // When no listed edge is valid any more, every remaining pair has S = 0, i.e. the same key -0.0, and
 // the reference's order among them is numpy's unstable argsort (undefined); like the dense path and
 // the oracle, the lower flat index i*n + j wins: the smallest node that is still a fragment end takes
 // its smallest valid partner, until one path is left.  Negative sums (keys that would sort AFTER the
 // zeros) are reported (TSP2OPT_E_UNSUPPORTED) so that the caller can take the dense path.
 //
-// Workspace: 24 B per listed edge and instance for the structure + 20 (fp32 heat) or 28 (fp64) bytes per
+// Workspace: 28 B per listed edge and instance for the structure + 20 (fp32 heat) or 28 (fp64) bytes per
 // listed edge and heat map (two entries per edge: partner, fp32 key, sum) instead of 8 N^2.
 
 #include <hip/hip_runtime.h>
@@ -43,18 +44,45 @@ constexpr int kSpMaxRow = 8192;         // entries of one row the rank sorts acc
 
 // ---- structure phase ---------------------------------------------------------------------------------
 // blockIdx.y = instance in the structure kernels: its edge list ei + inst*2E, its rows at inst*(n+1), its
-// entries at inst*2E
-__global__ void k_sp_count(const int64_t* __restrict__ ei, int64_t E, int n, int* __restrict__ cnt, int* __restrict__ err)
+// entries at inst*2E.
+// Edge lists are usually source-major (k consecutive edges share their source), so a wave's source-side
+// atomics would all hit one or two counters: runs of equal consecutive sources are added by their first lane.
+struct SrcRun {
+    int head;               // first lane of this lane's run
+    int len;                // run length (meaningful in the head lane)
+};
+
+__device__ __forceinline__ SrcRun src_run(int key, int lane)
+{
+    const int prev = __shfl_up(key, 1);
+    const unsigned long long heads = __ballot(lane == 0 || prev != key);
+    const unsigned long long upto = heads & ((2ull << lane) - 1ull);        // lane 63: shift wraps to 0, mask = all
+    const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
+    SrcRun r;
+    r.head = 63 - __clzll((long long)upto);
+    r.len = (above ? lane + __ffsll((long long)above) : 64) - lane;         // head lane: distance to the next head
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_sp_count(const int64_t* __restrict__ ei, int64_t E, int n, int* __restrict__ cnt,
+                                                  int* __restrict__ err)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
+    const int lane = threadIdx.x & 63;
     ei += (size_t)blockIdx.y * 2 * (size_t)E;
     cnt += (size_t)blockIdx.y * ((size_t)n + 1);
-    const int64_t a = ei[e], b = ei[E + e];
-    if (a < 0 || a >= n || b < 0 || b >= n) { atomicOr(err, 1); return; }
-    if (a == b) return;                                 // the diagonal is never a valid edge
-    atomicAdd(&cnt[a], 1);
-    atomicAdd(&cnt[b], 1);
+    int64_t a = -1, b = -1;
+    if (e < E) {
+        a = ei[e];
+        b = ei[E + e];
+        if (a < 0 || a >= n || b < 0 || b >= n) { atomicOr(err, 1); a = -1; }
+    }
+    const bool valid = a >= 0 && a != b;                // the diagonal is never a valid edge
+    const SrcRun r = src_run(valid ? (int)a : -1 - lane, lane);
+    if (valid) {
+        if (r.head == lane) atomicAdd(&cnt[a], r.len);
+        atomicAdd(&cnt[b], 1);
+    }
 }
 
 // exclusive scan of cnt[0..n) into off[0..n], one block; also zeroes the fill cursors and checks the row cap
@@ -93,19 +121,29 @@ __global__ void __launch_bounds__(1024) k_sp_scan(const int* __restrict__ cnt, i
     if (tid == 1023) off[n] = part[1023];
 }
 
-__global__ void k_sp_fill(const int64_t* __restrict__ ei, int64_t E, int n, const int* __restrict__ off, int* __restrict__ cur,
-                          uint16_t* __restrict__ ent_j, int* __restrict__ ent_e)
+__global__ void __launch_bounds__(256) k_sp_fill(const int64_t* __restrict__ ei, int64_t E, int n, const int* __restrict__ off,
+                                                 int* __restrict__ cur, uint16_t* __restrict__ ent_j, int* __restrict__ ent_e)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
+    const int lane = threadIdx.x & 63;
     ei += (size_t)blockIdx.y * 2 * (size_t)E;
     off += (size_t)blockIdx.y * ((size_t)n + 1);
     cur += (size_t)blockIdx.y * ((size_t)n + 1);
     ent_j += (size_t)blockIdx.y * 2 * (size_t)E;
     ent_e += (size_t)blockIdx.y * 2 * (size_t)E;
-    const int64_t a = ei[e], b = ei[E + e];
-    if (a < 0 || a >= n || b < 0 || b >= n || a == b) return;
-    int pos = off[a] + atomicAdd(&cur[a], 1);
+    int64_t a = -1, b = -1;
+    if (e < E) {
+        a = ei[e];
+        b = ei[E + e];
+        if (a < 0 || a >= n || b < 0 || b >= n) a = -1;
+    }
+    const bool valid = a >= 0 && a != b;
+    const SrcRun r = src_run(valid ? (int)a : -1 - lane, lane);
+    int base = 0;
+    if (valid && r.head == lane) base = atomicAdd(&cur[a], r.len);
+    base = __shfl(base, r.head);
+    if (!valid) return;
+    int pos = off[a] + base + (lane - r.head);
     ent_j[pos] = (uint16_t)b;
     ent_e[pos] = (int)(2 * e);                          // row a holds (a, b): forward, the first coo matrix
     pos = off[b] + atomicAdd(&cur[b], 1);
@@ -113,10 +151,12 @@ __global__ void k_sp_fill(const int64_t* __restrict__ ei, int64_t E, int n, cons
     ent_e[pos] = (int)(2 * e + 1);                      // row b holds the same edge transposed: the second
 }
 
-// one wave per row: entries ordered by (partner, edge id, direction); ucnt[i] = distinct partners
+// one wave per row: entries ordered by (partner, edge id, direction); ucnt[i] = distinct partners, and
+// hd[o + h] = position in the row of the first entry of its h-th partner
 __global__ void __launch_bounds__(64) k_sp_rowsort(const int* __restrict__ off, const uint16_t* __restrict__ ent_j,
                                                    const int* __restrict__ ent_e, uint16_t* __restrict__ srt_j,
-                                                   int* __restrict__ srt_e, int* __restrict__ ucnt, int n, int64_t E)
+                                                   int* __restrict__ srt_e, uint16_t* __restrict__ hd,
+                                                   int* __restrict__ ucnt, int n, int64_t E)
 {
     const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= n) return;
@@ -126,6 +166,7 @@ __global__ void __launch_bounds__(64) k_sp_rowsort(const int* __restrict__ off, 
     ent_e += (size_t)blockIdx.y * 2 * (size_t)E;
     srt_j += (size_t)blockIdx.y * 2 * (size_t)E;
     srt_e += (size_t)blockIdx.y * 2 * (size_t)E;
+    hd += (size_t)blockIdx.y * 2 * (size_t)E;
     const int o = off[i], L = off[i + 1] - o;
     for (int x = lane; x < L; x += 64) {
         const unsigned long long kx = ((unsigned long long)ent_j[o + x] << 32) | (unsigned)ent_e[o + x];
@@ -139,20 +180,27 @@ __global__ void __launch_bounds__(64) k_sp_rowsort(const int* __restrict__ off, 
     }
     __syncthreads();
     int heads = 0;
-    for (int x = lane; x < L; x += 64) heads += (x == 0 || srt_j[o + x] != srt_j[o + x - 1]) ? 1 : 0;
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) heads += __shfl_xor(heads, s);
+    for (int x0 = 0; x0 < L; x0 += 64) {
+        const int x = x0 + lane;
+        const bool head = x < L && (x == 0 || srt_j[o + x] != srt_j[o + x - 1]);
+        const unsigned long long bal = __ballot(head);
+        if (head) hd[o + heads + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)x;
+        heads += __popcll(bal);
+    }
     if (lane == 0) ucnt[i] = heads;
 }
 
 // ---- per heat map: sums per partner, keys, candidate lists ---------------------------------------------
-// one wave per (row, heat map).  list_j / list_S [map][uoff[i] + rank]: partners with S > 0 by exact (key, j)
+// one wave per (row, heat map), a lane per distinct partner.  list_j / list_k / list_S [map][uoff[i] + rank]:
+// partners with S > 0 by exact (key, j)
 template <typename H>
 __global__ void __launch_bounds__(64) k_sp_rowkeys(const H* __restrict__ vals, const double* __restrict__ points,
                                                    const int* __restrict__ off, const uint16_t* __restrict__ srt_j,
-                                                   const int* __restrict__ srt_e, const int* __restrict__ uoff,
+                                                   const int* __restrict__ srt_e, const uint16_t* __restrict__ hd,
+                                                   const int* __restrict__ uoff,
                                                    uint16_t* __restrict__ list_j, float* __restrict__ list_k,
-                                                   H* __restrict__ list_S, int* __restrict__ len, int n, int64_t E, int mpi, int* __restrict__ err)
+                                                   H* __restrict__ list_S, int* __restrict__ len, int n, int64_t E,
+                                                   int mpi, int cap, int* __restrict__ err)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int i = blockIdx.x, lane = threadIdx.x;
@@ -162,19 +210,26 @@ __global__ void __launch_bounds__(64) k_sp_rowkeys(const H* __restrict__ vals, c
     uoff += inst * ((size_t)n + 1);
     srt_j += inst * E2;
     srt_e += inst * E2;
+    hd += inst * E2;
     const int o = off[i], L = off[i + 1] - o;
-    double* hk = reinterpret_cast<double*>(smem);                       // keys of the run heads (+inf: dropped)
-    H* hs = reinterpret_cast<H*>(smem + sizeof(double) * (size_t)L);
+    const int ub = uoff[i], U = uoff[i + 1] - ub;
+    double* ck = reinterpret_cast<double*>(smem);                       // kept partners, compact: key, sum, node
+    H* cS = reinterpret_cast<H*>(smem + sizeof(double) * (size_t)cap);
+    uint16_t* cj = reinterpret_cast<uint16_t*>(smem + (sizeof(double) + sizeof(H)) * (size_t)cap);
     const H* v = vals + (size_t)m * (size_t)E;
     const double* P = points + inst * (size_t)n * 2;
     const double xi = P[2 * i], yi = P[2 * i + 1];
-    for (int x = lane; x < L; x += 64) {
-        const int j = srt_j[o + x];
+    int K = 0;
+    for (int h0 = 0; h0 < U; h0 += 64) {
+        const int h = h0 + lane;
         double key = INFINITY;
         H S = (H)0;
-        if (x == 0 || srt_j[o + x - 1] != j) {                          // run head: sum the run
+        int j = 0;
+        if (h < U) {
+            const int xs = hd[o + h], xe = h + 1 < U ? (int)hd[o + h + 1] : L;
+            j = srt_j[o + xs];
             H fwd = (H)0, bwd = (H)0;
-            for (int y = x; y < L && srt_j[o + y] == j; ++y) {
+            for (int y = xs; y < xe; ++y) {                             // the entries of one pair, by edge id
                 const int e2 = srt_e[o + y];
                 const H w = v[e2 >> 1];
                 if (e2 & 1) bwd += w; else fwd += w;
@@ -187,32 +242,33 @@ __global__ void __launch_bounds__(64) k_sp_rowkeys(const H* __restrict__ vals, c
                 if (key != key) key = INFINITY;
             }
         }
-        hk[x] = key;
-        hs[x] = S;
+        const bool keep = key != INFINITY;
+        const unsigned long long bal = __ballot(keep);
+        if (keep) {
+            const int c = K + __popcll(bal & ((1ull << lane) - 1ull));
+            ck[c] = key;
+            cS[c] = S;
+            cj[c] = (uint16_t)j;
+        }
+        K += __popcll(bal);
     }
     __syncthreads();
-    int kept = 0;
-    H* outS = list_S + (size_t)m * E2 + uoff[i];
-    uint16_t* outJ = list_j + (size_t)m * E2 + uoff[i];
-    float* outK = list_k + (size_t)m * E2 + uoff[i];
-    for (int x = lane; x < L; x += 64) {
-        const double kx = hk[x];
-        if (kx == INFINITY) continue;
-        const unsigned jx = srt_j[o + x];
+    H* outS = list_S + (size_t)m * E2 + ub;
+    uint16_t* outJ = list_j + (size_t)m * E2 + ub;
+    float* outK = list_k + (size_t)m * E2 + ub;
+    for (int c = lane; c < K; c += 64) {
+        const double kc = ck[c];
+        const unsigned jc = cj[c];
         int rank = 0;
-        for (int y = 0; y < L; ++y) {
-            const double ky = hk[y];
-            if (ky == INFINITY) continue;
-            rank += (ky < kx || (ky == kx && (unsigned)srt_j[o + y] < jx)) ? 1 : 0;
+        for (int y = 0; y < K; ++y) {
+            const double ky = ck[y];
+            rank += (ky < kc || (ky == kc && (unsigned)cj[y] < jc)) ? 1 : 0;
         }
-        outJ[rank] = (uint16_t)jx;
-        outK[rank] = (float)kx;                                         // what the merge loop compares first
-        outS[rank] = hs[x];
-        ++kept;
+        outJ[rank] = (uint16_t)jc;
+        outK[rank] = (float)kc;                                         // what the merge loop compares first
+        outS[rank] = cS[c];
     }
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) kept += __shfl_xor(kept, s);
-    if (lane == 0) len[(size_t)m * n + i] = kept;
+    if (lane == 0) len[(size_t)m * n + i] = K;
 }
 
 // ---- merge loop ------------------------------------------------------------------------------------------
@@ -248,45 +304,32 @@ __device__ __forceinline__ bool sp_ok(const SpLds& L, int i, int oe, int j)
     return L.deg[j] < 2 && !(j == oe && oe != i);
 }
 
-// node i's candidate is gone: the next valid entry of its list, or none (all lanes)
+// node i's candidate is gone: the next valid entry of its list, or none.  One thread per node: the partners
+// are fetched four at a time so that a run of dead entries costs one memory latency per four
 template <typename H>
-__device__ __forceinline__ void sp_advance(const SpLds& L, const SpMap<H>& M, int i, int lane)
+__device__ __forceinline__ void sp_advance(const SpLds& L, const SpMap<H>& M, int i, int oe)
 {
-    const unsigned p0 = L.pos[i] + 1;
-    const int rem = L.rem[i], oe = L.oend[i];
-    for (int q0 = 0; q0 < rem; q0 += 64) {
-        const int q = q0 + lane;
-        int j = 0;
-        float k = 0.f;
-        bool ok = false;
-        if (q < rem) { j = M.lj[p0 + q]; k = M.lk[p0 + q]; ok = sp_ok(L, i, oe, j); }
-        const unsigned long long bal = __ballot(ok);
-        if (bal) {
-            if (lane == __ffsll((long long)bal) - 1) {
-                L.pos[i] = p0 + (unsigned)q;
-                L.rem[i] = (uint16_t)(rem - q - 1);
-                L.key[i] = k;
-                L.cj[i] = (uint16_t)j;
+    unsigned p = L.pos[i] + 1;
+    int rem = L.rem[i];
+    while (rem > 0) {
+        int j[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = u < rem ? (int)M.lj[p + u] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u < rem && sp_ok(L, i, oe, j[u])) {
+                L.pos[i] = p + (unsigned)u;
+                L.rem[i] = (uint16_t)(rem - u - 1);
+                L.cj[i] = (uint16_t)j[u];
+                L.key[i] = M.lk[p + u];
+                return;
             }
-            return;
         }
+        p += 4;
+        rem -= 4;
     }
-    if (lane == 0) {
-        L.rem[i] = 0;
-        L.key[i] = __builtin_nanf("");
-    }
-}
-
-__device__ __forceinline__ void sp_refresh_group(const SpLds& L, int n, int x, int lane, float& gm0, float& gm1, float& gm2)
-{
-    const int g = x >> 6, k = (g << 6) + lane;
-    const float v = k < n ? L.key[k] : __builtin_nanf("");
-    const float m = wave_min(v != v ? INFINITY : v);
-    if (lane == (g & 63)) {
-        if (g < 64) gm0 = m;
-        else if (g < 128) gm1 = m;
-        else gm2 = m;
-    }
+    L.rem[i] = 0;
+    L.key[i] = __builtin_nanf("");
 }
 
 __device__ __forceinline__ void sp_link(const SpLds& L, uint16_t* nb, int i, int j)
@@ -303,24 +346,39 @@ __device__ __forceinline__ void sp_link(const SpLds& L, uint16_t* nb, int i, int
     L.oend[oj] = (uint16_t)oi;
 }
 
+// One workgroup per heat map.  The sequential rule "insert the valid edge with the smallest (key, flat index)"
+// is carried out in ROUNDS that insert many edges at once.  After every node's candidate has been moved to its
+// first valid entry, an edge f = (i, j) is inserted in this round when
+//   * it is the candidate of both i and j (no valid edge at i or j precedes it: the lists are exactly ordered), and
+//   * the far ends a, b of the two fragments it joins hold candidates with strictly larger fp32 keys (or none):
+//     then nothing can happen at i, j, a or b before f's turn, so f is valid at its turn, and the only edge
+//     whose validity f changes, (a, b), comes after it -- moving f to the front changes no other decision.
+// Edges chosen in one round join disjoint pairs of fragments, so a thread each applies them.  The valid edge
+// with the globally smallest key always qualifies unless another candidate has the same fp32 key; a round
+// that finds nothing therefore inserts exactly that edge after comparing the tied ones exactly (double key,
+// then flat index), the serial rule.  Cursor advances (the only global-memory reads of the loop) run one
+// node per thread, so their latencies overlap.
 template <typename H>
-__global__ void __launch_bounds__(64) k_greedy_sparse(const uint16_t* __restrict__ list_j, const float* __restrict__ list_k,
-                                                      const H* __restrict__ list_S,
-                                                      const int* __restrict__ len, const int* __restrict__ uoff,
-                                                      const double* __restrict__ points, uint16_t* __restrict__ nbg,
-                                                      int64_t* __restrict__ tours, int64_t num_maps, int n, int64_t E,
-                                                      int mpi, unsigned long long* __restrict__ dbg)
+__global__ void __launch_bounds__(1024) k_greedy_sparse(const uint16_t* __restrict__ list_j, const float* __restrict__ list_k,
+                                                        const H* __restrict__ list_S,
+                                                        const int* __restrict__ len, const int* __restrict__ uoff,
+                                                        const double* __restrict__ points, uint16_t* __restrict__ nbg,
+                                                        int64_t* __restrict__ tours, int64_t num_maps, int n, int64_t E,
+                                                        int mpi, unsigned long long* __restrict__ dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float red_f[16];
+    __shared__ double red_e[16];
+    __shared__ unsigned red_i[16];
+    __shared__ int ctl[2];                              // edges chosen this round; any candidate left
     const int64_t b = blockIdx.x;
     if (b >= num_maps) return;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = T >> 6;
     const int G = (n + 63) >> 6;
     const size_t inst = (size_t)(b / mpi), E2 = 2 * (size_t)E;
     uoff += inst * ((size_t)n + 1);
-    const int U = uoff[n];
     const unsigned long long t0 = wall_clock64();
-    unsigned long long passes = 0, advances = 0, tie_runs = 0;
+    unsigned long long rounds = 0, serial_rounds = 0;
     SpLds L;
     size_t o = 0;
     L.key = reinterpret_cast<float*>(smem + o); o += sizeof(float) * (size_t)n;
@@ -333,7 +391,7 @@ __global__ void __launch_bounds__(64) k_greedy_sparse(const uint16_t* __restrict
                points + inst * (size_t)n * 2, n};
     const int* lenm = len + (size_t)b * n;
     uint16_t* nb = nbg + (size_t)b * 2 * (size_t)n;
-    for (int i = lane; i < n; i += 64) {
+    for (int i = tid; i < n; i += T) {
         L.oend[i] = (uint16_t)i;
         L.deg[i] = 0;
         nb[2 * i] = nb[2 * i + 1] = 0xffffu;
@@ -344,72 +402,95 @@ __global__ void __launch_bounds__(64) k_greedy_sparse(const uint16_t* __restrict
         L.key[i] = li > 0 ? M.lk[base] : __builtin_nanf("");       // first candidates: the heads of the lists
         L.cj[i] = li > 0 ? M.lj[base] : (uint16_t)0;
     }
-    __builtin_amdgcn_wave_barrier();
-    float gm0 = INFINITY, gm1 = INFINITY, gm2 = INFINITY;
-    for (int g = 0; g < G; ++g) sp_refresh_group(L, n, g << 6, lane, gm0, gm1, gm2);
-    __builtin_amdgcn_wave_barrier();
+    if (tid == 0) ctl[0] = ctl[1] = 0;
+    __syncthreads();
 
     int merges = 0;
     const unsigned long long t1 = wall_clock64();
-    // ---- listed edges: every pass merges or replaces one node's candidate
-    for (long long guard = 0; merges < n - 1 && guard < 4ll * U + 4ll * n + 1024; ++guard) {
-        const float m = wave_min(fminf(fminf(gm0, gm1), gm2));
-        if (!(m < INFINITY)) break;                     // no listed edge is valid any more
-        ++passes;
-        unsigned long long gb0 = __ballot(gm0 == m), gb1 = __ballot(gm1 == m), gb2 = __ballot(gm2 == m);
-        int i = -1, second = -1, hits = 0;
-        unsigned cji = 0, cjs = 0;
-        while (gb0 | gb1 | gb2) {                       // groups whose minimum is m (usually one)
-            int g;
-            if (gb0) { g = __ffsll((long long)gb0) - 1; gb0 &= gb0 - 1; }
-            else if (gb1) { g = 64 + __ffsll((long long)gb1) - 1; gb1 &= gb1 - 1; }
-            else { g = 128 + __ffsll((long long)gb2) - 1; gb2 &= gb2 - 1; }
-            const int k = (g << 6) + lane;
-            const float ck = k < n ? L.key[k] : __builtin_nanf("");
-            const unsigned ccj = k < n ? L.cj[k] : 0u;
-            unsigned long long bal = __ballot(ck == m);
-            hits += __popcll(bal);
-            while (bal && second < 0) {
-                const int src = __ffsll((long long)bal) - 1;
-                bal &= bal - 1;
-                const unsigned cc = (unsigned)__builtin_amdgcn_readlane((int)ccj, src);
-                if (i < 0) { i = (g << 6) + src; cji = cc; } else { second = (g << 6) + src; cjs = cc; }
-            }
+    // ---- listed edges
+    for (int guard = 0; merges < n - 1 && guard < n + 8; ++guard) {
+        // (1) every open node's candidate becomes its first valid entry
+        if (tid == 0) ctl[0] = ctl[1] = 0;              // last read before the barrier that ended the previous round
+        for (int i = tid; i < n; i += T) {
+            const float k = L.key[i];
+            if (k != k) continue;                       // none (also: degree 2)
+            const int oe = L.oend[i];
+            if (!sp_ok(L, i, oe, L.cj[i])) sp_advance(L, M, i, oe);
         }
-        if (hits == 0) break;
-        if (hits > 1 && !(hits == 2 && cji == (unsigned)second && cjs == (unsigned)i)) {
-            // different edges with the same fp32 key: exact keys, recomputed from the listed sums
-            ++tie_runs;
+        __syncthreads();
+        // (2) choose: the lower endpoint of an edge decides and marks itself (top bit of rem)
+        int mine = 0;
+        bool any = false;
+        for (int i = tid; i < n; i += T) {
+            const float k = L.key[i];
+            if (k != k) continue;
+            any = true;
+            const int j = L.cj[i];
+            if (j < i || L.cj[j] != i) continue;
+            const float kj = L.key[j];
+            if (kj != kj) continue;
+            const int a = L.oend[i], c = L.oend[j];
+            if (a != i && L.key[a] <= k) continue;      // NaN (no candidate) compares false: passes
+            if (c != j && L.key[c] <= k) continue;
+            L.rem[i] |= 0x8000u;
+            ++mine;
+        }
+        if (any) ctl[1] = 1;
+        if (mine) atomicAdd(&ctl[0], mine);
+        __syncthreads();
+        const int chosen = ctl[0];
+        if (!ctl[1]) break;                             // no listed edge is valid any more
+        ++rounds;
+        if (chosen) {
+            // (3) apply: disjoint fragments, one thread per edge
+            for (int i = tid; i < n; i += T) {
+                const unsigned r = L.rem[i];
+                if (r & 0x8000u) {
+                    L.rem[i] = (uint16_t)(r & 0x7fffu);
+                    sp_link(L, nb, i, L.cj[i]);
+                }
+            }
+            merges += chosen;
+        } else {
+            // the smallest fp32 key is shared by different edges: exact keys from the listed sums, then the
+            // flat index -- one edge, like the serial scan
+            ++serial_rounds;
+            float lm = INFINITY;
+            for (int i = tid; i < n; i += T) {
+                const float k = L.key[i];
+                if (k == k) lm = fminf(lm, k);
+            }
+            lm = wave_min(lm);
+            if (lane == 0) red_f[wv] = lm;
+            __syncthreads();
+            float m = INFINITY;
+            for (int w = 0; w < nw; ++w) m = fminf(m, red_f[w]);
             double bk = INFINITY;
             unsigned bf = 0xffffffffu;
-            for (int k = lane; k < n; k += 64) {
-                if (!(L.key[k] == m)) continue;
-                const unsigned cj = L.cj[k];
-                const unsigned f = (unsigned)k * (unsigned)n + cj;
-                const double key = sp_key(M, k, (int)cj, M.lS[L.pos[k]]);
+            for (int i = tid; i < n; i += T) {
+                if (!(L.key[i] == m)) continue;
+                const unsigned cj = L.cj[i];
+                const unsigned f = (unsigned)i * (unsigned)n + cj;
+                const double key = sp_key(M, i, (int)cj, M.lS[L.pos[i]]);
                 if (better(key, f, bk, bf)) { bk = key; bf = f; }
             }
             wave_best(bk, bf);
-            i = (int)(bf / (unsigned)n);
-            cji = bf - (unsigned)i * (unsigned)n;
-        }
-        const int j = (int)cji;
-        const bool valid = sp_ok(L, i, L.oend[i], j);
-        if (valid) {
-            if (lane == 0) sp_link(L, nb, i, j);
+            if (lane == 0) { red_e[wv] = bk; red_i[wv] = bf; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 0; w < nw; ++w)
+                    if (better(red_e[w], red_i[w], bk, bf)) { bk = red_e[w]; bf = red_i[w]; }
+                if (bf != 0xffffffffu) {
+                    const int i = (int)(bf / (unsigned)n);
+                    sp_link(L, nb, i, (int)(bf - (unsigned)i * (unsigned)n));
+                }
+            }
             ++merges;
-            __builtin_amdgcn_wave_barrier();
-            // an end that is still open keeps its (now stale or still fine) candidate: it is checked when taken
-            sp_refresh_group(L, n, i, lane, gm0, gm1, gm2);
-            if ((j >> 6) != (i >> 6)) sp_refresh_group(L, n, j, lane, gm0, gm1, gm2);
-        } else {
-            ++advances;
-            sp_advance(L, M, i, lane);
-            __builtin_amdgcn_wave_barrier();
-            sp_refresh_group(L, n, i, lane, gm0, gm1, gm2);
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     }
+    __syncthreads();
+    if (tid >= 64) return;                              // the rest is short and serial: wave 0
     // ---- unlisted pairs: all have the key -0.0, the lower flat index i*n + j goes first: the smallest
     // fragment end takes its smallest valid partner.  Both only ever move up: i is the smallest open node (it
     // stays open after its first unlisted merge when it had degree 0), its partner is the smallest open node
@@ -466,17 +547,20 @@ __global__ void __launch_bounds__(64) k_greedy_sparse(const uint16_t* __restrict
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    if (lane == 0) {
+    if (lane < 2) {
+        // lane 0 walks from node 0 towards its larger neighbour and fills positions 1 .. n/2, lane 1 walks the
+        // other way round and fills n-1 .. n/2+1
         int64_t* t = tours + (size_t)b * (size_t)(n + 1);
+        const int h = n >> 1, steps = lane == 0 ? h : n - 1 - h;
         int prev = -1, cur = 0;
-        t[0] = 0;
-        for (int k = 1; k <= n; ++k) {
+        if (lane == 0) { t[0] = 0; t[n] = 0; }
+        for (int s2 = 1; s2 <= steps; ++s2) {
             const unsigned w = nbl[cur];
             const int n0 = (int)(w & 0xffffu), n1 = (int)(w >> 16);
             int best = -1;
             if (n0 != 0xffff && n0 != prev) best = n0;
-            if (n1 != 0xffff && n1 != prev && n1 > best) best = n1;
-            t[k] = best;
+            if (n1 != 0xffff && n1 != prev && (s2 == 1 && lane == 1 ? (best < 0 || n1 < best) : n1 > best)) best = n1;
+            t[lane == 0 ? s2 : n - s2] = best;
             prev = cur;
             cur = best < 0 ? 0 : best;
         }
@@ -484,13 +568,13 @@ __global__ void __launch_bounds__(64) k_greedy_sparse(const uint16_t* __restrict
     if (b == 0 && lane == 0 && dbg) {                   // diagnostics of heat map 0 (10 ns ticks, counts)
         const unsigned long long t4 = wall_clock64();
         dbg[0] = t1 - t0; dbg[1] = t2 - t1; dbg[2] = t3 - t2; dbg[3] = t4 - t3;
-        dbg[4] = passes; dbg[5] = advances; dbg[6] = tie_runs; dbg[7] = (unsigned long long)listed_merges;
+        dbg[4] = rounds; dbg[5] = serial_rounds; dbg[6] = 0; dbg[7] = (unsigned long long)listed_merges;
     }
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------
 struct SpWs {
-    size_t off_err, off_cnt, off_off, off_cur, off_ucnt, off_uoff, off_entj, off_ente, off_srtj, off_srte,
+    size_t off_err, off_cnt, off_off, off_cur, off_ucnt, off_uoff, off_entj, off_ente, off_srtj, off_srte, off_hd,
         off_len, off_nb, off_lj, off_lk, off_lS, total;
 };
 
@@ -510,6 +594,7 @@ SpWs sp_ws(int64_t num_maps, int64_t inst, int n, int64_t E, int hsz)
     w.off_ente = o; o += up(E2 * inst * 4);
     w.off_srtj = o; o += up(E2 * inst * 2);
     w.off_srte = o; o += up(E2 * inst * 4);
+    w.off_hd = o; o += up(E2 * inst * 2);
     w.off_len = o; o += up((size_t)num_maps * n * 4);
     w.off_nb = o; o += up((size_t)num_maps * n * 4);
     w.off_lj = o; o += up((size_t)num_maps * E2 * 2);
@@ -536,6 +621,7 @@ int greedy_sparse_t(const void* values, const int64_t* ei, const double* points,
     int* ente = reinterpret_cast<int*>(w8 + wl.off_ente);
     uint16_t* srtj = reinterpret_cast<uint16_t*>(w8 + wl.off_srtj);
     int* srte = reinterpret_cast<int*>(w8 + wl.off_srte);
+    uint16_t* hd = reinterpret_cast<uint16_t*>(w8 + wl.off_hd);
     int* len = reinterpret_cast<int*>(w8 + wl.off_len);
     uint16_t* nb = reinterpret_cast<uint16_t*>(w8 + wl.off_nb);
     uint16_t* lj = reinterpret_cast<uint16_t*>(w8 + wl.off_lj);
@@ -547,11 +633,11 @@ int greedy_sparse_t(const void* values, const int64_t* ei, const double* points,
     hipLaunchKernelGGL(k_sp_count, dim3(eg, ig), dim3(256), 0, stream, ei, E, n, cnt, err);
     hipLaunchKernelGGL(k_sp_scan, dim3(ig), dim3(1024), 0, stream, cnt, off, cur, n, kSpMaxRow, err);
     hipLaunchKernelGGL(k_sp_fill, dim3(eg, ig), dim3(256), 0, stream, ei, E, n, off, cur, entj, ente);
-    hipLaunchKernelGGL(k_sp_rowsort, dim3((unsigned)n, ig), dim3(64), 0, stream, off, entj, ente, srtj, srte, ucnt, n, E);
+    hipLaunchKernelGGL(k_sp_rowsort, dim3((unsigned)n, ig), dim3(64), 0, stream, off, entj, ente, srtj, srte, hd, ucnt, n, E);
     hipLaunchKernelGGL(k_sp_scan, dim3(ig), dim3(1024), 0, stream, ucnt, uoff, (int*)nullptr, n, 0, err);
     HIP_TRY(hipGetLastError());
     // a row's keys and sums are staged in LDS: rows are capped at kSpMaxRow entries (checked on the device)
-    const size_t rlds = (size_t)kSpMaxRow * (sizeof(double) + sizeof(H));
+    const size_t rlds = (size_t)kSpMaxRow * (sizeof(double) + sizeof(H) + 2);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_rowkeys<H>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
     int eh[2] = {0, 0};
@@ -561,14 +647,15 @@ int greedy_sparse_t(const void* values, const int64_t* ei, const double* points,
     if (errh & 1) return fail(TSP2OPT_E_ARG, "edge_index has an entry outside [0, n)");
     if (errh & 2) return fail(TSP2OPT_E_UNSUPPORTED, "a node has more than 8192 listed edges: use the dense decoder");
     // the longest row bounds the LDS request of the key kernel (one wave per row: short rows, many per CU)
-    const size_t klds = ((size_t)std::max(eh[1], 1) * (sizeof(double) + sizeof(H)) + 15) & ~(size_t)15;
+    const int cap = std::max(eh[1], 1);
+    const size_t klds = ((size_t)cap * (sizeof(double) + sizeof(H) + 2) + 15) & ~(size_t)15;
     hipLaunchKernelGGL(k_sp_rowkeys<H>, dim3((unsigned)n, (unsigned)num_maps), dim3(64), klds, stream,
-                       static_cast<const H*>(values), points, off, srtj, srte, uoff, lj, lk, lS, len, n, E, mpi, err);
+                       static_cast<const H*>(values), points, off, srtj, srte, hd, uoff, lj, lk, lS, len, n, E, mpi, cap, err);
     HIP_TRY(hipGetLastError());
     const size_t lds = (size_t)n * 15 + 64;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_sparse<H>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_greedy_sparse<H>, dim3((unsigned)num_maps), dim3(64), lds, stream, lj, lk, lS, len, uoff, points,
+    hipLaunchKernelGGL(k_greedy_sparse<H>, dim3((unsigned)num_maps), dim3(n > 2048 ? 1024 : 256), lds, stream, lj, lk, lS, len, uoff, points,
                        nb, tours, num_maps, n, E, mpi, reinterpret_cast<unsigned long long*>(err + 16));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&errh, err, 4, hipMemcpyDeviceToHost, stream));

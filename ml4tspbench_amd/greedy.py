@@ -84,7 +84,7 @@ def greedy_decode_sparse_device(values: torch.Tensor, edge_index: torch.Tensor, 
     _lib.check(rc, "tsp2opt_greedy_decode_sparse")
     if return_diagnostics:
         d = ws[64:128].cpu().numpy().view("uint64")
-        names = ("setup_ticks", "listed_ticks", "unlisted_ticks", "walk_ticks", "passes", "advances", "tie_runs",
+        names = ("setup_ticks", "listed_ticks", "unlisted_ticks", "walk_ticks", "rounds", "serial_rounds", "reserved",
                  "listed_merges")
         return tours, {k: int(v) for k, v in zip(names, d)}
     return tours

@@ -185,7 +185,7 @@ def test_gpu_sparse_greedy_batch_of_instances(dtype):
     vals = torch.from_numpy(np.concatenate([d[2] for d in data])).to(dev)
     got, diag = greedy_decode_sparse_device(vals, ei, pts, maps_per_instance=maps, return_diagnostics=True)
     got = got.cpu().numpy()
-    assert diag["passes"] > 0 and diag["listed_merges"] <= n - 1
+    assert diag["rounds"] > 0 and diag["listed_merges"] <= n - 1
     for q, (p, e, v) in enumerate(data):
         ref = greedy_oracle.greedy(p, greedy_oracle.densify(v, e, n))
         assert np.array_equal(got[q * maps:(q + 1) * maps], ref), q
