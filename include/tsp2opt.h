@@ -177,8 +177,8 @@ int64_t tsp2opt_greedy_workspace_bytes(int64_t num_maps, int32_t n, int32_t heat
  *              a pair are summed like the reference's coo matrices do.  The reference decodes one instance
  *              per call (num_instances = 1); a batch runs all its instances side by side
  *   points, tours_out, maps_per_instance: as tsp2opt_greedy_decode
- * Every node keeps the complete, exactly ordered list of its listed partners (workspace: 28 B per listed
- * edge and instance + 20 or 28 B per listed edge and heat map, instead of 8 n^2 per heat map); pairs that are not listed
+ * Every node keeps the complete, exactly ordered list of its listed partners (workspace: 12 B per listed
+ * edge and instance + 12 B per listed edge and heat map, instead of 8 n^2 per heat map); pairs that are not listed
  * all have the key -0.0 and are taken, after every listed edge, in flat-index order -- the tie rule of the
  * dense entry point and of the oracle (the reference's order among equal keys is numpy's unstable argsort).
  * A listed pair whose heat sum is negative (its key would sort after the unlisted pairs) or a node with more

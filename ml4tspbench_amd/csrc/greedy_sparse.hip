@@ -23,8 +23,8 @@
 // its smallest valid partner, until one path is left.  Negative sums (keys that would sort AFTER the
 // zeros) are reported (TSP2OPT_E_UNSUPPORTED) so that the caller can take the dense path.
 //
-// Workspace: 28 B per listed edge and instance for the structure + 20 (fp32 heat) or 28 (fp64) bytes per
-// listed edge and heat map (two entries per edge: partner, fp32 key, sum) instead of 8 N^2.
+// Workspace: 12 B per listed edge and instance for the sorted rows + 12 B per listed edge and heat map for
+// the lists (two entries per edge: partner, fp32 key) instead of 8 N^2.
 
 #include <hip/hip_runtime.h>
 
@@ -151,12 +151,12 @@ __global__ void __launch_bounds__(256) k_sp_fill(const int64_t* __restrict__ ei,
     ent_e[pos] = (int)(2 * e + 1);                      // row b holds the same edge transposed: the second
 }
 
-// one wave per row: entries ordered by (partner, edge id, direction); ucnt[i] = distinct partners, and
-// hd[o + h] = position in the row of the first entry of its h-th partner
+// one wave per row: entries ordered by (partner, edge id, direction); ucnt[i] = distinct partners, and the
+// first entry of every partner carries bit 31 of its srt_e word (edge ids stay below 2^30)
+constexpr int kHeadBit = (int)0x80000000u;
 __global__ void __launch_bounds__(64) k_sp_rowsort(const int* __restrict__ off, const uint16_t* __restrict__ ent_j,
                                                    const int* __restrict__ ent_e, uint16_t* __restrict__ srt_j,
-                                                   int* __restrict__ srt_e, uint16_t* __restrict__ hd,
-                                                   int* __restrict__ ucnt, int n, int64_t E)
+                                                   int* __restrict__ srt_e, int* __restrict__ ucnt, int n, int64_t E)
 {
     const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= n) return;
@@ -166,7 +166,6 @@ __global__ void __launch_bounds__(64) k_sp_rowsort(const int* __restrict__ off, 
     ent_e += (size_t)blockIdx.y * 2 * (size_t)E;
     srt_j += (size_t)blockIdx.y * 2 * (size_t)E;
     srt_e += (size_t)blockIdx.y * 2 * (size_t)E;
-    hd += (size_t)blockIdx.y * 2 * (size_t)E;
     const int o = off[i], L = off[i + 1] - o;
     for (int x = lane; x < L; x += 64) {
         const unsigned long long kx = ((unsigned long long)ent_j[o + x] << 32) | (unsigned)ent_e[o + x];
@@ -183,9 +182,8 @@ __global__ void __launch_bounds__(64) k_sp_rowsort(const int* __restrict__ off, 
     for (int x0 = 0; x0 < L; x0 += 64) {
         const int x = x0 + lane;
         const bool head = x < L && (x == 0 || srt_j[o + x] != srt_j[o + x - 1]);
-        const unsigned long long bal = __ballot(head);
-        if (head) hd[o + heads + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)x;
-        heads += __popcll(bal);
+        if (head) srt_e[o + x] |= kHeadBit;
+        heads += __popcll(__ballot(head));
     }
     if (lane == 0) ucnt[i] = heads;
 }
@@ -196,11 +194,10 @@ __global__ void __launch_bounds__(64) k_sp_rowsort(const int* __restrict__ off, 
 template <typename H>
 __global__ void __launch_bounds__(64) k_sp_rowkeys(const H* __restrict__ vals, const double* __restrict__ points,
                                                    const int* __restrict__ off, const uint16_t* __restrict__ srt_j,
-                                                   const int* __restrict__ srt_e, const uint16_t* __restrict__ hd,
-                                                   const int* __restrict__ uoff,
+                                                   const int* __restrict__ srt_e, const int* __restrict__ uoff,
                                                    uint16_t* __restrict__ list_j, float* __restrict__ list_k,
-                                                   H* __restrict__ list_S, int* __restrict__ len, int n, int64_t E,
-                                                   int mpi, int cap, int* __restrict__ err)
+                                                   int* __restrict__ len, int n, int64_t E, int mpi, int cap,
+                                                   int* __restrict__ err)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int i = blockIdx.x, lane = threadIdx.x;
@@ -210,12 +207,20 @@ __global__ void __launch_bounds__(64) k_sp_rowkeys(const H* __restrict__ vals, c
     uoff += inst * ((size_t)n + 1);
     srt_j += inst * E2;
     srt_e += inst * E2;
-    hd += inst * E2;
     const int o = off[i], L = off[i + 1] - o;
-    const int ub = uoff[i], U = uoff[i + 1] - ub;
-    double* ck = reinterpret_cast<double*>(smem);                       // kept partners, compact: key, sum, node
-    H* cS = reinterpret_cast<H*>(smem + sizeof(double) * (size_t)cap);
-    uint16_t* cj = reinterpret_cast<uint16_t*>(smem + (sizeof(double) + sizeof(H)) * (size_t)cap);
+    const int ub = uoff[i];
+    double* ck = reinterpret_cast<double*>(smem);                       // kept partners, compact: key, node
+    uint16_t* cj = reinterpret_cast<uint16_t*>(smem + sizeof(double) * (size_t)cap);
+    uint16_t* hd = cj + cap;                                            // first entry of the h-th partner
+    int U = 0;
+    for (int x0 = 0; x0 < L; x0 += 64) {
+        const int x = x0 + lane;
+        const bool head = x < L && srt_e[o + x] < 0;
+        const unsigned long long bal = __ballot(head);
+        if (head) hd[U + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)x;
+        U += __popcll(bal);
+    }
+    __syncthreads();
     const H* v = vals + (size_t)m * (size_t)E;
     const double* P = points + inst * (size_t)n * 2;
     const double xi = P[2 * i], yi = P[2 * i + 1];
@@ -226,11 +231,11 @@ __global__ void __launch_bounds__(64) k_sp_rowkeys(const H* __restrict__ vals, c
         H S = (H)0;
         int j = 0;
         if (h < U) {
-            const int xs = hd[o + h], xe = h + 1 < U ? (int)hd[o + h + 1] : L;
+            const int xs = hd[h], xe = h + 1 < U ? (int)hd[h + 1] : L;
             j = srt_j[o + xs];
             H fwd = (H)0, bwd = (H)0;
             for (int y = xs; y < xe; ++y) {                             // the entries of one pair, by edge id
-                const int e2 = srt_e[o + y];
+                const int e2 = srt_e[o + y] & ~kHeadBit;
                 const H w = v[e2 >> 1];
                 if (e2 & 1) bwd += w; else fwd += w;
             }
@@ -247,13 +252,11 @@ __global__ void __launch_bounds__(64) k_sp_rowkeys(const H* __restrict__ vals, c
         if (keep) {
             const int c = K + __popcll(bal & ((1ull << lane) - 1ull));
             ck[c] = key;
-            cS[c] = S;
             cj[c] = (uint16_t)j;
         }
         K += __popcll(bal);
     }
     __syncthreads();
-    H* outS = list_S + (size_t)m * E2 + ub;
     uint16_t* outJ = list_j + (size_t)m * E2 + ub;
     float* outK = list_k + (size_t)m * E2 + ub;
     for (int c = lane; c < K; c += 64) {
@@ -266,7 +269,6 @@ __global__ void __launch_bounds__(64) k_sp_rowkeys(const H* __restrict__ vals, c
         }
         outJ[rank] = (uint16_t)jc;
         outK[rank] = (float)kc;                                         // what the merge loop compares first
-        outS[rank] = cS[c];
     }
     if (lane == 0) len[(size_t)m * n + i] = K;
 }
@@ -287,8 +289,11 @@ template <typename H>
 struct SpMap {
     const uint16_t* lj;     // this heat map's lists
     const float* lk;
-    const H* lS;
     const double* P;
+    const H* v;             // for the exact keys of tied candidates: the heat values and the instance's rows
+    const int* off;
+    const uint16_t* sj;
+    const int* se;
     int n;
 };
 
@@ -297,6 +302,25 @@ __device__ __forceinline__ double sp_key(const SpMap<H>& M, int i, int j, H S)
 {
     const double dx = M.P[2 * i] - M.P[2 * j], dy = M.P[2 * i + 1] - M.P[2 * j + 1];
     return -(double)S / sqrt(dx * dx + dy * dy);
+}
+
+// exact key of the listed pair (i, j): its sum rebuilt from row i's entries exactly as k_sp_rowkeys adds them
+template <typename H>
+__device__ double sp_exact_key(const SpMap<H>& M, int i, int j)
+{
+    const int o = M.off[i], L = M.off[i + 1] - o;
+    int lo = 0, hi = L;
+    while (lo < hi) {                                   // first entry of partner j (rows are sorted by partner)
+        const int mid = (lo + hi) >> 1;
+        if ((int)M.sj[o + mid] < j) lo = mid + 1; else hi = mid;
+    }
+    H fwd = (H)0, bwd = (H)0;
+    for (int y = lo; y < L && (int)M.sj[o + y] == j; ++y) {
+        const int e2 = M.se[o + y] & ~kHeadBit;
+        const H w = M.v[e2 >> 1];
+        if (e2 & 1) bwd += w; else fwd += w;
+    }
+    return sp_key(M, i, j, (H)(fwd + bwd));
 }
 
 __device__ __forceinline__ bool sp_ok(const SpLds& L, int i, int oe, int j)
@@ -360,7 +384,8 @@ __device__ __forceinline__ void sp_link(const SpLds& L, uint16_t* nb, int i, int
 // node per thread, so their latencies overlap.
 template <typename H>
 __global__ void __launch_bounds__(1024) k_greedy_sparse(const uint16_t* __restrict__ list_j, const float* __restrict__ list_k,
-                                                        const H* __restrict__ list_S,
+                                                        const H* __restrict__ vals, const int* __restrict__ off,
+                                                        const uint16_t* __restrict__ srt_j, const int* __restrict__ srt_e,
                                                         const int* __restrict__ len, const int* __restrict__ uoff,
                                                         const double* __restrict__ points, uint16_t* __restrict__ nbg,
                                                         int64_t* __restrict__ tours, int64_t num_maps, int n, int64_t E,
@@ -387,8 +412,8 @@ __global__ void __launch_bounds__(1024) k_greedy_sparse(const uint16_t* __restri
     L.oend = reinterpret_cast<uint16_t*>(smem + o); o += sizeof(uint16_t) * (size_t)n;
     L.rem = reinterpret_cast<uint16_t*>(smem + o); o += sizeof(uint16_t) * (size_t)n;
     L.deg = reinterpret_cast<uint8_t*>(smem + o);
-    SpMap<H> M{list_j + (size_t)b * E2, list_k + (size_t)b * E2, list_S + (size_t)b * E2,
-               points + inst * (size_t)n * 2, n};
+    SpMap<H> M{list_j + (size_t)b * E2, list_k + (size_t)b * E2, points + inst * (size_t)n * 2,
+               vals + (size_t)b * (size_t)E, off + inst * ((size_t)n + 1), srt_j + inst * E2, srt_e + inst * E2, n};
     const int* lenm = len + (size_t)b * n;
     uint16_t* nb = nbg + (size_t)b * 2 * (size_t)n;
     for (int i = tid; i < n; i += T) {
@@ -471,7 +496,7 @@ __global__ void __launch_bounds__(1024) k_greedy_sparse(const uint16_t* __restri
                 if (!(L.key[i] == m)) continue;
                 const unsigned cj = L.cj[i];
                 const unsigned f = (unsigned)i * (unsigned)n + cj;
-                const double key = sp_key(M, i, (int)cj, M.lS[L.pos[i]]);
+                const double key = sp_exact_key(M, i, (int)cj);
                 if (better(key, f, bk, bf)) { bk = key; bf = f; }
             }
             wave_best(bk, bf);
@@ -574,11 +599,13 @@ __global__ void __launch_bounds__(1024) k_greedy_sparse(const uint16_t* __restri
 
 // ---- host ---------------------------------------------------------------------------------------------------
 struct SpWs {
-    size_t off_err, off_cnt, off_off, off_cur, off_ucnt, off_uoff, off_entj, off_ente, off_srtj, off_srte, off_hd,
-        off_len, off_nb, off_lj, off_lk, off_lS, total;
+    size_t off_err, off_cnt, off_off, off_cur, off_ucnt, off_uoff, off_srtj, off_srte, off_len, off_nb, off_lists,
+        off_lk, off_entj, off_ente, total;
 };
 
-SpWs sp_ws(int64_t num_maps, int64_t inst, int n, int64_t E, int hsz)
+// the unsorted entries (dead once the rows are sorted) share their memory with the candidate lists (written
+// afterwards): 12 B per listed edge and instance against 12 B per listed edge and heat map
+SpWs sp_ws(int64_t num_maps, int64_t inst, int n, int64_t E)
 {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     SpWs w{};
@@ -590,16 +617,17 @@ SpWs sp_ws(int64_t num_maps, int64_t inst, int n, int64_t E, int hsz)
     w.off_cur = o; o += up(N1 * 4);
     w.off_ucnt = o; o += up(N1 * 4);
     w.off_uoff = o; o += up(N1 * 4);
-    w.off_entj = o; o += up(E2 * inst * 2);
-    w.off_ente = o; o += up(E2 * inst * 4);
     w.off_srtj = o; o += up(E2 * inst * 2);
     w.off_srte = o; o += up(E2 * inst * 4);
-    w.off_hd = o; o += up(E2 * inst * 2);
     w.off_len = o; o += up((size_t)num_maps * n * 4);
     w.off_nb = o; o += up((size_t)num_maps * n * 4);
-    w.off_lj = o; o += up((size_t)num_maps * E2 * 2);
-    w.off_lk = o; o += up((size_t)num_maps * E2 * 4);
-    w.off_lS = o; o += up((size_t)num_maps * E2 * (size_t)hsz);
+    w.off_lists = o;
+    w.off_lk = o + up((size_t)num_maps * E2 * 2);                       // list_j, then list_k
+    const size_t lists = up((size_t)num_maps * E2 * 2) + up((size_t)num_maps * E2 * 4);
+    w.off_entj = o;
+    w.off_ente = o + up(E2 * inst * 2);
+    const size_t ents = up(E2 * inst * 2) + up(E2 * inst * 4);
+    o += std::max(lists, ents);
     w.total = o;
     return w;
 }
@@ -609,7 +637,7 @@ int greedy_sparse_t(const void* values, const int64_t* ei, const double* points,
                     int n, int64_t E, int mpi, void* ws, hipStream_t stream)
 {
     const int64_t inst = (num_maps + mpi - 1) / mpi;
-    const SpWs wl = sp_ws(num_maps, inst, n, E, (int)sizeof(H));
+    const SpWs wl = sp_ws(num_maps, inst, n, E);
     unsigned char* w8 = static_cast<unsigned char*>(ws);
     int* err = reinterpret_cast<int*>(w8 + wl.off_err);
     int* cnt = reinterpret_cast<int*>(w8 + wl.off_cnt);
@@ -621,23 +649,21 @@ int greedy_sparse_t(const void* values, const int64_t* ei, const double* points,
     int* ente = reinterpret_cast<int*>(w8 + wl.off_ente);
     uint16_t* srtj = reinterpret_cast<uint16_t*>(w8 + wl.off_srtj);
     int* srte = reinterpret_cast<int*>(w8 + wl.off_srte);
-    uint16_t* hd = reinterpret_cast<uint16_t*>(w8 + wl.off_hd);
     int* len = reinterpret_cast<int*>(w8 + wl.off_len);
     uint16_t* nb = reinterpret_cast<uint16_t*>(w8 + wl.off_nb);
-    uint16_t* lj = reinterpret_cast<uint16_t*>(w8 + wl.off_lj);
+    uint16_t* lj = reinterpret_cast<uint16_t*>(w8 + wl.off_lists);
     float* lk = reinterpret_cast<float*>(w8 + wl.off_lk);
-    H* lS = reinterpret_cast<H*>(w8 + wl.off_lS);
     HIP_TRY(hipMemsetAsync(w8, 0, wl.off_off, stream));                 // err + cnt
     const unsigned eg = (unsigned)std::max<int64_t>((E + 255) / 256, 1);   // E = 0: one idle block
     const unsigned ig = (unsigned)inst;
     hipLaunchKernelGGL(k_sp_count, dim3(eg, ig), dim3(256), 0, stream, ei, E, n, cnt, err);
     hipLaunchKernelGGL(k_sp_scan, dim3(ig), dim3(1024), 0, stream, cnt, off, cur, n, kSpMaxRow, err);
     hipLaunchKernelGGL(k_sp_fill, dim3(eg, ig), dim3(256), 0, stream, ei, E, n, off, cur, entj, ente);
-    hipLaunchKernelGGL(k_sp_rowsort, dim3((unsigned)n, ig), dim3(64), 0, stream, off, entj, ente, srtj, srte, hd, ucnt, n, E);
+    hipLaunchKernelGGL(k_sp_rowsort, dim3((unsigned)n, ig), dim3(64), 0, stream, off, entj, ente, srtj, srte, ucnt, n, E);
     hipLaunchKernelGGL(k_sp_scan, dim3(ig), dim3(1024), 0, stream, ucnt, uoff, (int*)nullptr, n, 0, err);
     HIP_TRY(hipGetLastError());
     // a row's keys and sums are staged in LDS: rows are capped at kSpMaxRow entries (checked on the device)
-    const size_t rlds = (size_t)kSpMaxRow * (sizeof(double) + sizeof(H) + 2);
+    const size_t rlds = (size_t)kSpMaxRow * (sizeof(double) + 4);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_rowkeys<H>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
     int eh[2] = {0, 0};
@@ -648,14 +674,15 @@ int greedy_sparse_t(const void* values, const int64_t* ei, const double* points,
     if (errh & 2) return fail(TSP2OPT_E_UNSUPPORTED, "a node has more than 8192 listed edges: use the dense decoder");
     // the longest row bounds the LDS request of the key kernel (one wave per row: short rows, many per CU)
     const int cap = std::max(eh[1], 1);
-    const size_t klds = ((size_t)cap * (sizeof(double) + sizeof(H) + 2) + 15) & ~(size_t)15;
+    const size_t klds = ((size_t)cap * (sizeof(double) + 4) + 15) & ~(size_t)15;
     hipLaunchKernelGGL(k_sp_rowkeys<H>, dim3((unsigned)n, (unsigned)num_maps), dim3(64), klds, stream,
-                       static_cast<const H*>(values), points, off, srtj, srte, hd, uoff, lj, lk, lS, len, n, E, mpi, cap, err);
+                       static_cast<const H*>(values), points, off, srtj, srte, uoff, lj, lk, len, n, E, mpi, cap, err);
     HIP_TRY(hipGetLastError());
     const size_t lds = (size_t)n * 15 + 64;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_sparse<H>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_greedy_sparse<H>, dim3((unsigned)num_maps), dim3(n > 2048 ? 1024 : 256), lds, stream, lj, lk, lS, len, uoff, points,
+    hipLaunchKernelGGL(k_greedy_sparse<H>, dim3((unsigned)num_maps), dim3(n > 2048 ? 1024 : 256), lds, stream, lj, lk,
+                       static_cast<const H*>(values), off, srtj, srte, len, uoff, points,
                        nb, tours, num_maps, n, E, mpi, reinterpret_cast<unsigned long long*>(err + 16));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&errh, err, 4, hipMemcpyDeviceToHost, stream));
@@ -676,7 +703,7 @@ extern "C" int64_t tsp2opt_greedy_sparse_workspace_bytes(int64_t num_maps, int32
     if (num_maps < 0 || n < 2 || num_edges < 0 || maps_per_instance < 1) return fail(TSP2OPT_E_ARG, "bad size");
     if (heat_dtype != TSP2OPT_DTYPE_F32 && heat_dtype != TSP2OPT_DTYPE_F64) return fail(TSP2OPT_E_ARG, "bad dtype");
     const int64_t inst = (num_maps + maps_per_instance - 1) / maps_per_instance;
-    return (int64_t)sp_ws(num_maps, inst, n, num_edges, heat_dtype == TSP2OPT_DTYPE_F64 ? 8 : 4).total;
+    return (int64_t)sp_ws(num_maps, inst, n, num_edges).total;
 }
 
 extern "C" int tsp2opt_greedy_decode_sparse(const void* values, const int64_t* edge_index, const double* points,

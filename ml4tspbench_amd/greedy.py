@@ -48,12 +48,15 @@ def greedy_decode_device(heat: torch.Tensor, points: torch.Tensor, *, maps_per_i
 
 
 def greedy_decode_sparse_device(values: torch.Tensor, edge_index: torch.Tensor, points: torch.Tensor, *,
-                                maps_per_instance: int = 1, return_diagnostics: bool = False):
+                                maps_per_instance: int = 1, return_diagnostics: bool = False,
+                                workspace_limit_bytes: int = 1 << 30):
     """Sparse heat maps without densifying them: values (B, E) float32/float64, edge_index (I, 2, E) integer
     (one list per instance, shared by its maps_per_instance heat maps; (2, E) for a single instance),
     points (I, N, 2), all on one HIP device, B == I * maps_per_instance.
     Returns tours (B, N+1) int64 on the device.  Raises ``Tsp2optError`` (code -2) for inputs the sparse
-    kernels do not take (negative heat sums, a node with more than 8192 listed edges): densify then."""
+    kernels do not take (negative heat sums, a node with more than 8192 listed edges): densify then.
+    The batch is decoded in as few library calls as keep each call's workspace (24 B per listed edge at one
+    heat map per instance) under ``workspace_limit_bytes``; a single instance is never split."""
     if values.device.type != "cuda" or points.device != values.device:
         raise ValueError("values and points must live on the same HIP device")
     if points.dim() == 2:
@@ -64,7 +67,8 @@ def greedy_decode_sparse_device(values: torch.Tensor, edge_index: torch.Tensor, 
         edge_index = edge_index.unsqueeze(0)
     B, E = values.shape
     I, n = points.shape[0], points.shape[1]
-    if tuple(edge_index.shape) != (I, 2, E) or B != I * maps_per_instance:
+    mpi = int(maps_per_instance)
+    if tuple(edge_index.shape) != (I, 2, E) or B != I * mpi:
         raise ValueError("expected values (I * maps_per_instance, E), edge_index (I, 2, E) and points (I, N, 2)")
     if values.dtype not in (torch.float32, torch.float64):
         values = values.to(torch.float32)
@@ -74,15 +78,24 @@ def greedy_decode_sparse_device(values: torch.Tensor, edge_index: torch.Tensor, 
     dev = values.device
     code = _lib.DTYPE_F64 if values.dtype == torch.float64 else _lib.DTYPE_F32
     L = _lib.lib()
-    need = L.tsp2opt_greedy_sparse_workspace_bytes(B, n, E, int(maps_per_instance), code)
-    _lib.check(need, "tsp2opt_greedy_sparse_workspace_bytes")
-    ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+    one = L.tsp2opt_greedy_sparse_workspace_bytes(mpi, n, E, mpi, code)
+    _lib.check(one, "tsp2opt_greedy_sparse_workspace_bytes")
+    per_call = max(1, min(I, int(workspace_limit_bytes) // max(int(one), 1), 65535 // mpi))
     tours = torch.empty((B, n + 1), dtype=torch.int64, device=dev)
-    rc = L.tsp2opt_greedy_decode_sparse(values.data_ptr(), ei.data_ptr(), pts.data_ptr(), tours.data_ptr(), B, n, E,
-                                        int(maps_per_instance), code, dev.index, ws.data_ptr(), ws.numel(),
-                                        torch.cuda.current_stream(dev).cuda_stream)
-    _lib.check(rc, "tsp2opt_greedy_decode_sparse")
-    if return_diagnostics:
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = None
+    for q0 in range(0, I, per_call):
+        q1 = min(I, q0 + per_call)
+        need = L.tsp2opt_greedy_sparse_workspace_bytes((q1 - q0) * mpi, n, E, mpi, code)
+        _lib.check(need, "tsp2opt_greedy_sparse_workspace_bytes")
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+        rc = L.tsp2opt_greedy_decode_sparse(values[q0 * mpi:q1 * mpi].data_ptr(), ei[q0:q1].data_ptr(),
+                                            pts[q0:q1].data_ptr(), tours[q0 * mpi:q1 * mpi].data_ptr(),
+                                            (q1 - q0) * mpi, n, E, mpi, code, dev.index, ws.data_ptr(), ws.numel(),
+                                            stream)
+        _lib.check(rc, "tsp2opt_greedy_decode_sparse")
+    if return_diagnostics:                                  # of the last call's first heat map
         d = ws[64:128].cpu().numpy().view("uint64")
         names = ("setup_ticks", "listed_ticks", "unlisted_ticks", "walk_ticks", "rounds", "serial_rounds", "reserved",
                  "listed_merges")

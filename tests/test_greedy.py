@@ -227,7 +227,7 @@ def test_gpu_sparse_greedy_front_end_and_fallbacks():
 def test_gpu_sparse_greedy_tsp10000_k50_full_size():
     """BASELINE.json configs[3]/[4] scale: 16 heat maps of 10 000 nodes with k = 50 listed neighbours stay a
     list (the dense decoder would need 12.8 GB of key matrices): valid tours that 2-opt improves, the workspace
-    stays under 400 MB, and two of the maps are checked against the dense HIP decoder."""
+    stays under 200 MB (100 MB in two calls), and two of the maps are checked against the dense HIP decoder."""
     from ml4tspbench_amd import greedy_decode_device, greedy_decode_sparse_device, two_opt_device, evaluate_tours, _lib
     n, k, maps = 10000, 50, 16
     dev = torch.device("cuda", 0)
@@ -244,7 +244,11 @@ def test_gpu_sparse_greedy_tsp10000_k50_full_size():
         del d
     tours = greedy_decode_sparse_device(torch.cat(vals_all), torch.stack(ei_all), pts)      # 16 instances, one call
     need = _lib.lib().tsp2opt_greedy_sparse_workspace_bytes(maps, n, n * k, 1, _lib.DTYPE_F32)
-    assert need < 400 * 2 ** 20, need                   # 44 B per listed edge (24 structure + 20 lists) vs 12.8 GB
+    assert need < 200 * 2 ** 20, need                   # 24 B per listed edge (12 sorted rows + 12 lists) vs 12.8 GB
+    # the same batch under a 100 MB workspace limit (two calls of 8 instances): identical tours
+    halves = greedy_decode_sparse_device(torch.cat(vals_all), torch.stack(ei_all), pts, workspace_limit_bytes=100 * 2 ** 20)
+    assert torch.equal(halves, tours)
+    assert _lib.lib().tsp2opt_greedy_sparse_workspace_bytes(8, n, n * k, 1, _lib.DTYPE_F32) < 100 * 2 ** 20
     ev0 = evaluate_tours(pts, tours)
     assert ((ev0.valid.cpu().numpy() & 7) == 7).all()
     res = two_opt_device(pts, tours, max_iterations=300)
