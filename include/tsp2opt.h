@@ -236,8 +236,9 @@ int tsp2opt_plan(int32_t n, int32_t dtype, int32_t device, int32_t* out7);
 
 /* Diagnostic, no counterpart in the reference: phase timers of the greedy decoder's merge loop.
  * enable = 1 zeroes and switches them on for `device`; enable = 0 switches them off and copies
- * out8 = {scan cycles, merge cycles, rescan cycles, merges, rescans, loop cycles, 0, 0} summed over
- * the heat maps decoded in between.  Synchronises the device. */
+ * out8 = {list-advance cycles, row-rescan cycles, choose+apply cycles, merges, rescans, loop cycles, rounds,
+ * rounds that inserted one exactly compared edge} summed over the heat maps decoded in between.
+ * Synchronises the device. */
 int tsp2opt_debug_greedy_cycles(int32_t enable, int32_t device, uint64_t* out8);
 
 /*

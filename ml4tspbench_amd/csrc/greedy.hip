@@ -9,23 +9,19 @@
 // The sort is never materialised here.  "Process the sorted list, skipping invalid edges" is the
 // same as "repeatedly take the best still-valid edge", and validity only ever decays (a node that
 // became interior stays interior, two nodes of one fragment stay in one fragment).  So every node
-// keeps one candidate -- its best valid partner when last looked at -- and each step takes the
-// minimum (key, flat index) over the endpoints' candidates: if that edge is still valid it is the
-// edge the sorted scan would insert next; if not, that node's row is rescanned.  About 3N steps of
-// O(N/64) work per lane instead of an N^2 log N sort.
+// keeps one candidate -- its best valid partner -- and the edges whose turn in the sorted scan nothing
+// can disturb any more are inserted together, many per round (see k_greedy): a few tens of rounds of
+// parallel work instead of an N^2 log N sort or 3N serial steps.
 //
 // Two kernels.  k_greedy_prepare (fully parallel) turns every heat map into the matrix of edge
 // keys, S = A + A^T formed on the fly through a tiled transpose so that A and A^T are both read
 // coalesced, and extracts every node's (up to) kTopK best partners in exact (key, index) order from the
-// two best entries each lane saw in its own columns.  k_greedy runs the merge loop, one WAVE per heat map (no workgroup barriers;
-// every step is a short latency chain and many heat maps run side by side on a CU), with per-map
-// state in LDS: the fp32 rounding of each node's candidate key and its partner, the node's short
-// candidate list and a cursor into it, degree, the other endpoint of each fragment, two neighbour
-// slots, and the minimum candidate key of every group of 64 nodes.  An invalidated candidate is
-// replaced by the next still-valid entry of the node's list (validity only decays, so skipped
-// entries never come back) -- LDS only, 3 of 4 replacements -- and by a rescan of the node's key row
-// (one global round trip) once the list is used up.  The best candidate over all nodes is the
-// minimum of the group minima; only the groups of the one or two nodes that changed are refreshed.
+// two best entries each lane saw in its own columns.  k_greedy runs the merge rounds, one workgroup per
+// heat map with 12 B of LDS state per node: the fp32 rounding of each node's candidate key and its partner,
+// a cursor into the node's short list, degree, the other endpoint of each fragment, and the queue of rows
+// to rescan.  An invalidated candidate is replaced by the next still-valid entry of the node's list
+// (validity only decays, so skipped entries never come back) and by a rescan of the node's key row once
+// the list is used up.
 //
 // Arithmetic follows the reference: S is summed in the heat map's dtype (numpy adds float32 arrays
 // in float32, greedy_search.py:36-38), keys are -double(S)/sqrt(dx*dx+dy*dy) in double
@@ -189,70 +185,46 @@ __global__ void __launch_bounds__(512) k_greedy_prepare(const H* __restrict__ A,
     }
 }
 
-// optional phase timers (tsp2opt_debug_greedy_cycles): [0] scan, [1] merge, [2] rescan cycles,
-// [3] merges, [4] rescans, [5] total cycles of the merge loop, summed over heat maps (lane 0)
+// optional counters (tsp2opt_debug_greedy_cycles), summed over heat maps by thread 0 of every workgroup:
+// cycles of [0] list advances, [1] row rescans, [2] choose + apply; [3] merges, [4] rescans, [5] total cycles
+// of the merge loop, [6] rounds, [7] rounds that inserted one exactly compared edge
 __device__ unsigned long long g_greedy_prof[8];
 
-struct Cand {               // node i's candidate edge i -> cj, one 8-byte LDS read
-    float key;              // fp32 rounding of its key; NaN = the node has no candidate (interior / none left)
-    unsigned cj;            // partner
-};
-
-struct GreedyLds {          // carve of the dynamic LDS for one heat map (one wave)
-    Cand* cand;
-    float* lk;              // K list entries per node: fp32 key (NaN = none) ...
-    uint16_t* lj;           // ... and partner (0xffff = none), exact (key, j) order
+struct RLds {               // carve of the dynamic LDS for one heat map, 12 B per node
+    float* key;             // fp32 rounding of the candidate's key; NaN = none (interior node, nothing valid)
+    uint16_t* cj;           // the candidate's partner
     uint16_t* oend;         // for a fragment endpoint: the fragment's other endpoint (itself if alone)
-    uint16_t* nb;           // 2 neighbour slots per node, 0xffff = empty
+    uint16_t* queue;        // rows to rescan this round
     uint8_t* deg;
-    uint8_t* lp;            // cursor into the node's list (K: list used up, candidates come from rescans)
-    int* cmd;               // NW > 1: row to rescan (or -1: done), published by wave 0 to the helper waves
-    struct Part* part;      // NW > 1: every wave's best valid partner of that row
+    uint8_t* lp;            // cursor into the node's list (kTopK: used up, candidates come from rescans);
+                            // bit 7: the node's candidate edge was chosen this round
 };
-
-struct Part {
-    double k;
-    unsigned j, pad;
-};
-
-// The minimum candidate key of every group of 64 nodes lives in registers: lane l holds groups l
-// (gm0), l + 64 (gm1) and, for n > 8192 (BIG kernels only), l + 128 (gm2); +inf = no candidate in the
-// group.  Refresh the minimum of node x's group after its candidate changed (all 64 lanes).
-template <bool BIG>
-__device__ __forceinline__ void refresh_group(const GreedyLds& L, int n, int x, int lane, float& gm0, float& gm1,
-                                              float& gm2)
-{
-    if (n <= 128) return;                               // two groups at most: scanned directly
-    const int g = x >> 6, k = (g << 6) + lane;
-    const float v = k < n ? L.cand[k].key : __builtin_nanf("");
-    const float m = wave_min(v != v ? INFINITY : v);
-    if (lane == (g & 63)) {
-        if (g < 64) gm0 = m;
-        else if (!BIG || g < 128) gm1 = m;
-        else gm2 = m;
-    }
-}
 
 // can node i still take partner j?  (j is a fragment endpoint of another fragment)
-__device__ __forceinline__ bool partner_ok(const GreedyLds& L, int i, int oe, int j)
+__device__ __forceinline__ bool partner_ok(const RLds& L, int i, int oe, int j)
 {
     return j != 0xffff && L.deg[j] < 2 && !(j == oe && oe != i);
 }
 
-// best valid partner of node i from its key row: minimum (key, j) over valid j.  All 64 lanes; the
-// row's keys are loaded unconditionally, W per lane in flight (8: n <= 512 in one global round trip
-// within 64 VGPRs, i.e. 8 heat maps per SIMD; 16 for larger n, where there are fewer maps than
-// SIMDs anyway).  Result stored by lane 0.
-// NW waves share a row: wave w takes the columns [64 W (w + NW t), 64 W (w + NW t + 1)), t = 0, 1, ...
-template <int W, int NW>
-__device__ __forceinline__ void rescan_part(const GreedyLds& L, const double* __restrict__ Kb, int n, int i, int lane,
-                                            int wave, double& bk, unsigned& bj)
+// best valid partner of node i from its key row: minimum (key, j) over valid j.  One wave per row; the
+// row's keys are loaded unconditionally, 16 per lane in flight.
+__device__ __forceinline__ void rescan_store(const RLds& L, int i, int lane, double bk, unsigned bj)
 {
+    wave_best(bk, bj);
+    if (lane == 0) {
+        L.key[i] = bj == 0xffffu ? __builtin_nanf("") : (float)bk;
+        L.cj[i] = (uint16_t)bj;
+    }
+}
+
+__device__ __forceinline__ void rescan_row(const RLds& L, const double* __restrict__ Kb, int n, int i, int lane)
+{
+    constexpr int W = 16;
     const double* Krow = Kb + (size_t)i * n;
     const int oe = L.oend[i];
-    bk = INFINITY;
-    bj = 0xffffu;
-    for (int j0 = wave * 64 * W + lane; j0 < n; j0 += 64 * W * NW) {
+    double bk = INFINITY;
+    unsigned bj = 0xffffu;
+    for (int j0 = lane; j0 < n; j0 += 64 * W) {
         double k[W];
 #pragma unroll
         for (int u = 0; u < W; ++u) k[u] = j0 + 64 * u < n ? Krow[j0 + 64 * u] : INFINITY;
@@ -263,295 +235,634 @@ __device__ __forceinline__ void rescan_part(const GreedyLds& L, const double* __
             if (k[u] < bk || (k[u] == bk && (unsigned)j < bj)) { bk = k[u]; bj = (unsigned)j; }
         }
     }
-    wave_best(bk, bj);
+    rescan_store(L, i, lane, bk, bj);
 }
 
-// wave 0's side of a rescan.  NW > 1 (large maps, one workgroup per heat map): the helper waves sleep
-// at a barrier between rescans (helper_loop); wave 0 publishes the row, everybody scans a share of it,
-// wave 0 reduces the NW partial results.
-template <int W, int NW>
-__device__ __forceinline__ void rescan(const GreedyLds& L, const double* __restrict__ Kb, int n, int i, int lane)
+// short rows (n <= 64 NL): the keys of 16 / NL queued rows are fetched in one global round trip, then every
+// row is reduced -- a rescan is a latency chain, and a workgroup has many of them per round
+template <int NL>
+__device__ __forceinline__ void rescan_rows(const RLds& L, const double* __restrict__ Kb, int n, int q0, int qn, int lane)
 {
-    double bk;
-    unsigned bj;
-    if constexpr (NW > 1) {
-        if (lane == 0) L.cmd[0] = i;
-        __syncthreads();
-        rescan_part<W, NW>(L, Kb, n, i, lane, 0, bk, bj);
-        __syncthreads();
-        if (lane >= 1 && lane < NW) { bk = L.part[lane].k; bj = L.part[lane].j; }
-        else if (lane != 0) { bk = INFINITY; bj = 0xffffu; }
-        wave_best(bk, bj);
-    } else {
-        rescan_part<W, 1>(L, Kb, n, i, lane, 0, bk, bj);
+    constexpr int R = 16 / NL;
+    int row[R];
+    double k[R][NL];
+#pragma unroll
+    for (int u = 0; u < R; ++u) row[u] = q0 + u < qn ? (int)L.queue[q0 + u] : -1;
+#pragma unroll
+    for (int u = 0; u < R; ++u)
+#pragma unroll
+        for (int v = 0; v < NL; ++v)
+            k[u][v] = (row[u] >= 0 && lane + 64 * v < n) ? Kb[(size_t)row[u] * n + lane + 64 * v] : INFINITY;
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        if (row[u] < 0) continue;                       // wave-uniform
+        const int i = row[u], oe = L.oend[i];
+        double bk = INFINITY;
+        unsigned bj = 0xffffu;
+#pragma unroll
+        for (int v = 0; v < NL; ++v) {
+            const int j = lane + 64 * v;
+            if (j >= n || j == i || !partner_ok(L, i, oe, j)) continue;
+            if (k[u][v] < bk || (k[u][v] == bk && (unsigned)j < bj)) { bk = k[u][v]; bj = (unsigned)j; }
+        }
+        rescan_store(L, i, lane, bk, bj);
     }
-    if (lane == 0) L.cand[i] = Cand{bj == 0xffffu ? __builtin_nanf("") : (float)bk, bj};
 }
 
-template <int W, int NW>
-__device__ __forceinline__ void helper_loop(const GreedyLds& L, const double* __restrict__ Kb, int n, int lane, int wave)
+__device__ __forceinline__ void link_nodes(const RLds& L, uint16_t* __restrict__ nb, int i, int j)
 {
-    for (;;) {
-        __syncthreads();                                // wave 0 has published a row, or the end
-        const int i = L.cmd[0];
-        if (i < 0) return;
-        double bk;
-        unsigned bj;
-        rescan_part<W, NW>(L, Kb, n, i, lane, wave, bk, bj);
-        if (lane == 0) L.part[wave] = Part{bk, bj, 0u};
-        __syncthreads();                                // partial results are in LDS
-    }
+    const int oi = L.oend[i], oj = L.oend[j];
+    const int di = L.deg[i], dj = L.deg[j];
+    nb[2 * i + di] = (uint16_t)j;               // slot = degree before the merge
+    nb[2 * j + dj] = (uint16_t)i;
+    L.deg[i] = (uint8_t)(di + 1);
+    L.deg[j] = (uint8_t)(dj + 1);
+    if (di >= 1) L.key[i] = __builtin_nanf("");
+    if (dj >= 1) L.key[j] = __builtin_nanf("");
+    L.oend[oi] = (uint16_t)oj;                  // the merged fragment runs from oi to oj
+    L.oend[oj] = (uint16_t)oi;
 }
 
-// node i's candidate is no longer valid: the next valid entry of its list, else a rescan
-__device__ __forceinline__ bool advance(const GreedyLds& L, int K, int i, int lane, const float* __restrict__ glk,
-                                        const uint16_t* __restrict__ glj)
-{
-    if (K == 0) {
-        // large n: no room for the lists in LDS, they are read where the prepare kernel left them (kTopK
-        // entries per node, one global round trip: still less than half of a row rescan)
-        const int p0 = L.lp[i], oe = L.oend[i];
-        if (p0 >= kTopK - 1) {
-            if (lane == 0) L.lp[i] = (uint8_t)kTopK;
-            return false;
-        }
-        float k = 0.f;
-        unsigned j = 0xffffu;
-        if (lane < kTopK) { k = glk[(size_t)i * kTopK + lane]; j = glj[(size_t)i * kTopK + lane]; }
-        const bool ok = lane > p0 && lane < kTopK && partner_ok(L, i, oe, (int)j);
-        const unsigned long long bal = __ballot(ok);
-        if (!bal) {
-            if (lane == 0) L.lp[i] = (uint8_t)kTopK;
-            return false;
-        }
-        const int p = __ffsll((long long)bal) - 1;
-        const float pk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, k), p));
-        const unsigned pj = (unsigned)__builtin_amdgcn_readlane((int)j, p);
-        if (lane == 0) {
-            L.lp[i] = (uint8_t)p;
-            L.cand[i] = Cand{pk, pj};
-        }
-        return true;
-    }
-    const int p0 = L.lp[i], oe = L.oend[i];
-    bool ok = false;
-    if (lane > p0 && lane < K) ok = partner_ok(L, i, oe, L.lj[i * K + lane]);
-    const unsigned long long bal = __ballot(ok);
-    if (!bal) {
-        if (lane == 0) L.lp[i] = (uint8_t)K;
-        return false;
-    }
-    const int p = __ffsll((long long)bal) - 1;
-    if (lane == 0) {
-        L.lp[i] = (uint8_t)p;
-        L.cand[i] = Cand{L.lk[i * K + p], L.lj[i * K + p]};
-    }
-    return true;
-}
-
-// K = list entries kept per node in LDS (kTopK, or fewer when n is large, none above kGreedyListMaxN);
-// W: see rescan (the W = 16 kernel is also the one that carries the third group-minimum register)
-// NW = waves per heat map: 1 (many maps side by side on a CU) or 16 for maps above kGreedyListMaxN
-// nodes, whose state fills a CU's LDS anyway and whose every replacement is a rescan of a long row
-template <int W, int NW>
-__global__ void __launch_bounds__(64 * NW) k_greedy(const double* __restrict__ Kd, const float* __restrict__ lkey,
-                                              const uint16_t* __restrict__ lj0, int64_t* __restrict__ tours,
-                                              int64_t num_maps, int n, int K, int prof)
+// The merge loop, one workgroup per heat map (64 threads for n <= 128, 256 up to 2048 nodes, 1024 above),
+// in ROUNDS that insert many edges at once (the same scheme as the sparse decoder, greedy_sparse.hip).
+// Every round first makes every open node's candidate its best VALID partner: the next valid entry of
+// its short list (a thread per node, lists read where the prepare kernel left them), else a rescan of its
+// key row (queued; a wave per queued row).  An edge f = (i, j) is then inserted when
+//   * it is the candidate of both i and j -- no valid edge at i or j precedes it -- and
+//   * the far ends a, b of the two fragments it joins hold candidates with strictly larger fp32 keys:
+//     nothing can happen at i, j, a or b before f's turn in the sorted scan, so f is valid at its turn, and
+//     the only edge whose validity f changes, (a, b), comes after it.
+// Edges chosen in one round join disjoint pairs of fragments: a thread each applies them.  The valid edge
+// with the globally smallest key always qualifies unless another candidate shares its fp32 key; a round
+// that finds nothing inserts exactly that edge after comparing the tied candidates exactly (double key from
+// the key matrix, then flat index): the serial rule.  A few tens of rounds replace about 3N serial steps.
+// NL: key loads per lane that cover a row (2, 4, 8 for n <= 128, 256, 512), 0 = longer rows
+template <int NL>
+__global__ void __launch_bounds__(1024) k_greedy(const double* __restrict__ Kd, const float* __restrict__ lkey,
+                                                 const uint16_t* __restrict__ lj0, uint16_t* __restrict__ nbg,
+                                                 int64_t* __restrict__ tours, int64_t num_maps, int n, int K, int prof)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float red_f[16];
+    __shared__ double red_e[16];
+    __shared__ unsigned red_i[16];
+    __shared__ int ctl[3];                              // edges chosen this round; any candidate left; queue length
     const int64_t b = blockIdx.x;
     if (b >= num_maps) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int G = (n + 63) >> 6;                        // groups of 64 nodes, <= 192
-    GreedyLds L;
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = T >> 6;
+    const int G = (n + 63) >> 6;
+    RLds L;
     size_t off = 0;
-    L.cand = reinterpret_cast<Cand*>(smem + off); off += sizeof(Cand) * (size_t)n;
-    L.lk = reinterpret_cast<float*>(smem + off); off += sizeof(float) * (size_t)n * K;
-    L.lj = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n * K;
+    L.key = reinterpret_cast<float*>(smem + off); off += sizeof(float) * (size_t)n;
+    L.cj = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n;
     L.oend = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n;
-    L.nb = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * 2 * (size_t)n;
+    L.queue = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n;
     L.deg = reinterpret_cast<uint8_t*>(smem + off); off += (size_t)n;
     L.lp = reinterpret_cast<uint8_t*>(smem + off);
-    off = (off + (size_t)n + 15) & ~(size_t)15;
-    L.cmd = reinterpret_cast<int*>(smem + off);         // NW > 1 only (greedy_lds)
-    L.part = reinterpret_cast<Part*>(smem + off + 16);
-    constexpr bool BIG = W == 16;
     const double* Kb = Kd + (size_t)b * (size_t)n * (size_t)n;
-    for (int i = threadIdx.x; i < n; i += 64 * NW) {
+    const float* glk = lkey + (size_t)b * (size_t)n * kTopK;
+    const uint16_t* glj = lj0 + (size_t)b * (size_t)n * kTopK;
+    uint16_t* nb = nbg + (size_t)b * 2 * (size_t)n;
+    for (int i = tid; i < n; i += T) {
         L.oend[i] = (uint16_t)i;
-        L.nb[2 * i] = L.nb[2 * i + 1] = 0xffffu;
         L.deg[i] = 0;
         L.lp[i] = 0;
-        const size_t src = ((size_t)b * n + i) * kTopK;
-        for (int p = 0; p < K; ++p) {
-            L.lk[i * K + p] = lkey[src + p];
-            L.lj[i * K + p] = lj0[src + p];
-        }
-        L.cand[i] = Cand{lkey[src], lj0[src]};          // first candidates: the heads of the lists
+        nb[2 * i] = nb[2 * i + 1] = 0xffffu;
+        L.key[i] = glk[(size_t)i * kTopK];              // first candidates: the heads of the lists
+        L.cj[i] = glj[(size_t)i * kTopK];
     }
-    if constexpr (NW > 1) {
-        __syncthreads();
-        if (wave != 0) { helper_loop<W, NW>(L, Kb, n, lane, wave); return; }
-    }
-    __builtin_amdgcn_wave_barrier();
-    float gm0 = INFINITY, gm1 = INFINITY, gm2 = INFINITY;
-    for (int g = 0; g < G; ++g) refresh_group<BIG>(L, n, g << 6, lane, gm0, gm1, gm2);
-    __builtin_amdgcn_wave_barrier();
+    if (tid == 0) ctl[0] = ctl[1] = ctl[2] = 0;
+    __syncthreads();
 
     int merges = 0;
-    unsigned long long t_scan = 0, t_merge = 0, t_rescan = 0, n_rescan = 0, t_begin = prof ? clock64() : 0;
-    // every pass either merges or replaces one node's candidate; a candidate is replaced at most once
-    // per change of its validity, so the loop ends (bounded anyway: never spin forever on bad input)
-    for (long long guard = 0; merges < n - 1 && guard < (long long)n * n + 1024; ++guard) {
-        // best candidate edge over all nodes: minimum of the group minima, then the nodes that attain
-        // it (fp32 roundings; NaN = no candidate, never equal); exact (key, flat index) comparison
-        // only when more than one node does and they do not simply name each other
+    unsigned long long t_adv = 0, t_resc = 0, t_apply = 0, n_resc = 0, rounds = 0, serial_rounds = 0;
+    const unsigned long long t_begin = prof ? clock64() : 0;
+    for (int guard = 0; merges < n - 1 && guard < n + 8; ++guard) {
         const unsigned long long t0 = prof ? clock64() : 0;
-        float m;
-        unsigned long long gb0 = 0ull, gb1 = 0ull, gb2 = 0ull;
-        int i = -1, second = -1, hits = 0;
-        unsigned cji = 0, cjs = 0;                      // partners of i and second
-        auto take = [&](unsigned long long bal, int base, unsigned cjl) {
-            while (bal && second < 0) {
-                const int src = __ffsll((long long)bal) - 1;
-                bal &= bal - 1;
-                const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)cjl, src);
-                if (i < 0) { i = base + src; cji = c; } else { second = base + src; cjs = c; }
+        // (1a) invalid candidates: the next valid list entry, else queue the row
+        if (tid == 0) ctl[0] = ctl[1] = 0;              // last read before the barrier that ended the previous round
+        for (int i = tid; i < n; i += T) {
+            const float k = L.key[i];
+            if (k != k) continue;                       // none (also: interior)
+            const int oe = L.oend[i];
+            if (partner_ok(L, i, oe, L.cj[i])) continue;
+            int p = L.lp[i];
+            bool found = false;
+            if (p + 1 < K) {
+                float lk[kTopK];
+                unsigned lj[kTopK];
+#pragma unroll
+                for (int u = 0; u < kTopK; ++u) { lk[u] = glk[(size_t)i * kTopK + u]; lj[u] = glj[(size_t)i * kTopK + u]; }
+#pragma unroll
+                for (int u = 1; u < kTopK; ++u) {
+                    if (!found && u > p && u < K && partner_ok(L, i, oe, (int)lj[u])) {
+                        found = true;
+                        L.key[i] = lk[u];
+                        L.cj[i] = (uint16_t)lj[u];
+                        L.lp[i] = (uint8_t)u;
+                    }
+                }
             }
-        };
-        if (n <= 128) {                                 // small maps: the candidates themselves
-            const Cand c0 = lane < n ? L.cand[lane] : Cand{__builtin_nanf(""), 0u};
-            const Cand c1 = lane + 64 < n ? L.cand[lane + 64] : Cand{__builtin_nanf(""), 0u};
-            m = wave_min(fminf(c0.key, c1.key));
-            const unsigned long long bal = __ballot(c0.key == m), bal1 = __ballot(c1.key == m);
-            hits = __popcll(bal) + __popcll(bal1);
-            take(bal, 0, c0.cj);
-            take(bal1, 64, c1.cj);
+            if (!found) {
+                L.lp[i] = (uint8_t)kTopK;
+                L.queue[atomicAdd(&ctl[2], 1)] = (uint16_t)i;
+            }
+        }
+        __syncthreads();
+        const unsigned long long t1 = prof ? clock64() : 0;
+        // (1b) queued rows: a wave each
+        const int qn = ctl[2];
+        if constexpr (NL > 0) {
+            for (int q0 = wv * (16 / NL); q0 < qn; q0 += nw * (16 / NL)) rescan_rows<NL>(L, Kb, n, q0, qn, lane);
         } else {
-            m = wave_min(BIG ? fminf(fminf(gm0, gm1), gm2) : fminf(gm0, gm1));
-            gb0 = __ballot(gm0 == m);
-            gb1 = __ballot(gm1 == m);
-            if (BIG) gb2 = __ballot(gm2 == m);
+            for (int q = wv; q < qn; q += nw) rescan_row(L, Kb, n, L.queue[q], lane);
         }
-        while (gb0 | gb1 | gb2) {                       // groups whose minimum is m (usually one)
-            int g;
-            if (gb0) { g = __ffsll((long long)gb0) - 1; gb0 &= gb0 - 1; }
-            else if (gb1) { g = 64 + __ffsll((long long)gb1) - 1; gb1 &= gb1 - 1; }
-            else { g = 128 + __ffsll((long long)gb2) - 1; gb2 &= gb2 - 1; }
-            const int k = (g << 6) + lane;
-            const Cand c = k < n ? L.cand[k] : Cand{__builtin_nanf(""), 0u};
-            const unsigned long long bal = __ballot(c.key == m);
-            hits += __popcll(bal);
-            take(bal, g << 6, c.cj);
+        n_resc += (unsigned long long)qn;
+        __syncthreads();
+        const unsigned long long t2 = prof ? clock64() : 0;
+        // (2) choose: the lower endpoint of an edge decides and marks itself
+        if (tid == 0) ctl[2] = 0;
+        int mine = 0;
+        bool any = false;
+        for (int i = tid; i < n; i += T) {
+            const float k = L.key[i];
+            if (k != k) continue;
+            any = true;
+            const int j = L.cj[i];
+            if (j < i || L.cj[j] != i) continue;
+            const float kj = L.key[j];
+            if (kj != kj) continue;
+            const int a = L.oend[i], c = L.oend[j];
+            if (a != i && L.key[a] <= k) continue;      // NaN (no candidate) compares false: passes
+            if (c != j && L.key[c] <= k) continue;
+            L.lp[i] |= 0x80u;
+            ++mine;
         }
-        if (hits == 0) break;                           // no valid edge left (cannot happen for n >= 2)
-        if (hits > 1 && !(hits == 2 && cji == (unsigned)second && cjs == (unsigned)i)) {
-            // different edges with the same fp32 key: exact keys from the key matrix.  (Two nodes that
-            // name each other are one edge with one key; the lower flat index is the lower node = i.)
+        if (any) ctl[1] = 1;
+        if (mine) atomicAdd(&ctl[0], mine);
+        __syncthreads();
+        const int chosen = ctl[0];
+        if (!ctl[1]) break;                             // no candidate anywhere (cannot happen for n >= 2)
+        ++rounds;
+        if (chosen) {
+            // (3) apply: disjoint fragments, one thread per edge
+            for (int i = tid; i < n; i += T) {
+                const unsigned r = L.lp[i];
+                if (r & 0x80u) {
+                    L.lp[i] = (uint8_t)(r & 0x7fu);
+                    link_nodes(L, nb, i, L.cj[i]);
+                }
+            }
+            merges += chosen;
+        } else {
+            // different edges share the smallest fp32 key: exact keys from the key matrix, then the flat index
+            ++serial_rounds;
+            float lm = INFINITY;
+            for (int i = tid; i < n; i += T) {
+                const float k = L.key[i];
+                if (k == k) lm = fminf(lm, k);
+            }
+            lm = wave_min(lm);
+            if (lane == 0) red_f[wv] = lm;
+            __syncthreads();
+            float m = INFINITY;
+            for (int w = 0; w < nw; ++w) m = fminf(m, red_f[w]);
             double bk = INFINITY;
             unsigned bf = 0xffffffffu;
-            for (int k = lane; k < n; k += 64) {
-                const Cand c = L.cand[k];
-                if (!(c.key == m)) continue;
-                const unsigned f = (unsigned)k * (unsigned)n + c.cj;
+            for (int i = tid; i < n; i += T) {
+                if (!(L.key[i] == m)) continue;
+                const unsigned f = (unsigned)i * (unsigned)n + L.cj[i];
                 const double key = Kb[f];
                 if (better(key, f, bk, bf)) { bk = key; bf = f; }
             }
             wave_best(bk, bf);
-            i = (int)(bf / (unsigned)n);
-            cji = bf - (unsigned)i * (unsigned)n;
-        }
-        const int j = (int)cji;
-        const int oi = L.oend[i], oj = L.oend[j];
-        const bool valid = L.deg[j] < 2 && !(oi == j && oi != i);
-        const unsigned long long t1 = prof ? clock64() : 0;
-        if (valid) {
-            if (lane == 0) {
-                L.nb[2 * i + (L.nb[2 * i] != 0xffffu)] = (uint16_t)j;
-                L.nb[2 * j + (L.nb[2 * j] != 0xffffu)] = (uint16_t)i;
-                const int di = L.deg[i] + 1, dj = L.deg[j] + 1;
-                L.deg[i] = (uint8_t)di;
-                L.deg[j] = (uint8_t)dj;
-                if (di >= 2) L.cand[i].key = __builtin_nanf("");
-                if (dj >= 2) L.cand[j].key = __builtin_nanf("");
-                L.oend[oi] = (uint16_t)oj;      // the merged fragment runs from oi to oj
-                L.oend[oj] = (uint16_t)oi;
+            if (lane == 0) { red_e[wv] = bk; red_i[wv] = bf; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 0; w < nw; ++w)
+                    if (better(red_e[w], red_i[w], bk, bf)) { bk = red_e[w]; bf = red_i[w]; }
+                if (bf != 0xffffffffu) {
+                    const int i = (int)(bf / (unsigned)n);
+                    link_nodes(L, nb, i, (int)(bf - (unsigned)i * (unsigned)n));
+                }
             }
             ++merges;
-            __builtin_amdgcn_wave_barrier();
-            refresh_group<BIG>(L, n, i, lane, gm0, gm1, gm2);
-            if ((j >> 6) != (i >> 6)) refresh_group<BIG>(L, n, j, lane, gm0, gm1, gm2);
-        } else {
-            if (!advance(L, K, i, lane, lkey + (size_t)b * n * kTopK, lj0 + (size_t)b * n * kTopK))
-                rescan<W, NW>(L, Kb, n, i, lane);
-            __builtin_amdgcn_wave_barrier();
-            refresh_group<BIG>(L, n, i, lane, gm0, gm1, gm2);
         }
-        __builtin_amdgcn_wave_barrier();
-        if (prof) {
-            const unsigned long long t2 = clock64();
-            t_scan += t1 - t0;
-            if (valid) t_merge += t2 - t1; else { t_rescan += t2 - t1; ++n_rescan; }
-        }
-    }
-    if constexpr (NW > 1) {                             // release the helper waves
-        if (lane == 0) L.cmd[0] = -1;
         __syncthreads();
-    }
-    if (prof && lane == 0) {
-        atomicAdd(&g_greedy_prof[0], t_scan);
-        atomicAdd(&g_greedy_prof[1], t_merge);
-        atomicAdd(&g_greedy_prof[2], t_rescan);
-        atomicAdd(&g_greedy_prof[3], (unsigned long long)merges);
-        atomicAdd(&g_greedy_prof[4], n_rescan);
-        atomicAdd(&g_greedy_prof[5], clock64() - t_begin);
-    }
-    // closing edge between the two remaining endpoints (cython_merge.pyx:99-102), then the walk of
-    // greedy_search.py:65-73: from node 0, never back to the previous node, larger index first
-    if (lane == 0) {
-        int a = -1, c = -1;
-        for (int i = 0; i < n; ++i)
-            if (L.deg[i] < 2) { if (a < 0) a = i; else c = i; }
-        if (a >= 0 && c >= 0) {
-            L.nb[2 * a + (L.nb[2 * a] != 0xffffu)] = (uint16_t)c;
-            L.nb[2 * c + (L.nb[2 * c] != 0xffffu)] = (uint16_t)a;
+        if (prof) {
+            const unsigned long long t3 = clock64();
+            t_adv += t1 - t0; t_resc += t2 - t1; t_apply += t3 - t2;
         }
+    }
+    __syncthreads();
+    if (prof && tid == 0) {
+        atomicAdd(&g_greedy_prof[0], t_adv);
+        atomicAdd(&g_greedy_prof[1], t_resc);
+        atomicAdd(&g_greedy_prof[2], t_apply);
+        atomicAdd(&g_greedy_prof[3], (unsigned long long)merges);
+        atomicAdd(&g_greedy_prof[4], n_resc);
+        atomicAdd(&g_greedy_prof[5], clock64() - t_begin);
+        atomicAdd(&g_greedy_prof[6], rounds);
+        atomicAdd(&g_greedy_prof[7], serial_rounds);
+    }
+    if (tid >= 64) return;                              // the rest is short and serial: wave 0
+    // closing edge between the two remaining endpoints (cython_merge.pyx:99-102), then the walk of
+    // greedy_search.py:65-73 (from node 0, never back to the previous node, larger index first) over an LDS
+    // copy of the neighbour table
+    int a = -1, c = -1;
+    for (int g = 0; g < G; ++g) {
+        const int k = (g << 6) + lane;
+        unsigned long long bal = __ballot(k < n && L.deg[k] < 2);
+        while (bal) {
+            const int k2 = (g << 6) + __ffsll((long long)bal) - 1;
+            bal &= bal - 1;
+            if (a < 0) a = k2; else c = k2;
+        }
+    }
+    __threadfence_block();
+    unsigned* nbl = reinterpret_cast<unsigned*>(L.key);    // the candidates are dead by now
+    for (int k = lane; k < n; k += 64) {
+        unsigned lo = nb[2 * k], hi = nb[2 * k + 1];
+        if (a >= 0 && c >= 0) {
+            if (k == a) { if (lo == 0xffffu) lo = (unsigned)c; else hi = (unsigned)c; }
+            if (k == c) { if (lo == 0xffffu) lo = (unsigned)a; else hi = (unsigned)a; }
+        }
+        nbl[k] = lo | (hi << 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (lane < 2) {
+        // lane 0 walks from node 0 towards its larger neighbour and fills positions 1 .. n/2, lane 1 walks the
+        // other way round and fills n-1 .. n/2+1
         int64_t* t = tours + (size_t)b * (size_t)(n + 1);
+        const int h = n >> 1, steps = lane == 0 ? h : n - 1 - h;
         int prev = -1, cur = 0;
-        t[0] = 0;
-        for (int k = 1; k <= n; ++k) {
-            const int n0 = L.nb[2 * cur], n1 = L.nb[2 * cur + 1];
+        if (lane == 0) { t[0] = 0; t[n] = 0; }
+        for (int s2 = 1; s2 <= steps; ++s2) {
+            const unsigned w = nbl[cur];
+            const int n0 = (int)(w & 0xffffu), n1 = (int)(w >> 16);
             int best = -1;
             if (n0 != 0xffff && n0 != prev) best = n0;
-            if (n1 != 0xffff && n1 != prev && n1 > best) best = n1;
-            t[k] = best;
+            if (n1 != 0xffff && n1 != prev && (s2 == 1 && lane == 1 ? (best < 0 || n1 < best) : n1 > best)) best = n1;
+            t[lane == 0 ? s2 : n - s2] = best;
             prev = cur;
             cur = best < 0 ? 0 : best;
         }
     }
 }
 
-constexpr int kGreedyListMaxN = 4500;   // lists of 2 fit the LDS of one wave's heat map up to here
-constexpr int kGreedyMaxN = 10200;      // 16 B of state per node in 160 KB; 160 groups of 64 nodes (<= 192)
-constexpr int kGreedyBigWaves = 16;     // waves per heat map above kGreedyListMaxN nodes
+// ---- small heat maps (n <= kGreedySmallN): one kernel, everything on chip -------------------------------
+// fp32 APPROXIMATIONS of a heat map's n^2 keys fit the LDS (40 KB at n = 100), so no key matrix goes to
+// memory: the workgroup reads its heat map once, keeps an fp32 key for every pair (the sum S in the heat
+// map's dtype as the reference forms it, the distance from the double coordinate differences rounded to
+// fp32: relative error below 2^-21), and runs the same rounds with row rescans out of LDS.  The fp32 keys
+// are only a filter with a margin: wherever a decision depends on two keys that are closer than 2^-19
+// relative (kGreedyTol, four times the error bound), the exact double keys are recomputed from the heat map
+// with the arithmetic of k_greedy_prepare and compared as (key, index).  Pairs whose fp32 evaluation leaves
+// the normal range (coincident points, overflow) get the fp32 rounding of the exact key, which is monotone.
+constexpr int kGreedySmallN = 128;
+constexpr float kGreedyTol = 1.9073486328125e-06f;      // 2^-19
 
-// list entries per node (extracted by the prepare kernel and kept in LDS by the merge loop): kTopK
-// while a heat map's state stays near 64 KB; 2 for larger n; none above kGreedyListMaxN (the state of
-// a TSP-10000 map alone is 160 KB: the lists stay in global memory); 1 (the row's best only) for small
-// n, where tracking and extracting more costs the prepare kernel more than the merge loop gains
-inline int greedy_k(int n) { return n <= 128 ? 1 : n <= 1700 ? kTopK : n <= kGreedyListMaxN ? 2 : 0; }
-// entries the prepare kernel extracts per node
-inline int greedy_rounds(int n) { return greedy_k(n) ? greedy_k(n) : kTopK; }
-
-inline size_t greedy_lds(int n)
+// the largest key that may still precede or tie one whose fp32 value is m
+__device__ __forceinline__ float amb_hi(float m)
 {
-    const int K = greedy_k(n);
-    return (size_t)n * (8 + 6 * (size_t)K + 2 + 4 + 1 + 1) + 64 +
-           (K ? 0 : 32 + sizeof(Part) * kGreedyBigWaves);
+    return fabsf(m) <= 3.0e38f ? m + fabsf(m) * kGreedyTol : m;
 }
 
+struct SLds {
+    float* Kf;              // the n (n - 1) / 2 keys of the pairs i < j, row-major triangle (see kf_at)
+    double* px;
+    double* py;
+    float* key;
+    unsigned* nbl;          // two 16-bit neighbour slots per node
+    uint16_t* cj;
+    uint16_t* oend;
+    uint16_t* queue;
+    uint8_t* deg;
+    uint8_t* flag;
+    int n;
+};
+
+// key of the pair {i, j}, i != j
+__device__ __forceinline__ float& kf_at(const SLds& L, int i, int j)
+{
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    return L.Kf[lo * (2 * L.n - lo - 1) / 2 + (hi - lo - 1)];
+}
+
+template <typename H>
+__device__ __forceinline__ double small_exact_key(const H* __restrict__ Ab, const SLds& L, int n, int i, int j)
+{
+    const H s = Ab[(size_t)i * n + j] + Ab[(size_t)j * n + i];
+    const double dx = L.px[i] - L.px[j], dy = L.py[i] - L.py[j];
+    const double k = -(double)s / sqrt(dx * dx + dy * dy);
+    return k != k ? INFINITY : k;
+}
+
+__device__ __forceinline__ bool small_ok(const SLds& L, int i, int oe, int j)
+{
+    return L.deg[j] < 2 && !(j == oe && oe != i);
+}
+
+// best valid partner of nodes ia and ib (ib < 0: none), one wave, the two latency chains interleaved: fp32
+// minimum over the node's keys, exact comparison among the entries within the margin
+template <typename H>
+__device__ __forceinline__ void small_rescan2(const SLds& L, const H* __restrict__ Ab, int n, int ia, int ib, int lane)
+{
+    const int row[2] = {ia, ib};
+    float k[2][2];
+    bool v[2][2];
+    float hi[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = row[u] < 0 ? 0 : row[u];
+        const int oe = L.oend[i];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int j = lane + 64 * w;
+            v[u][w] = row[u] >= 0 && j < n && j != i && small_ok(L, i, oe, j);
+            k[u][w] = v[u][w] ? kf_at(L, i, j) : INFINITY;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) hi[u] = amb_hi(wave_min(fminf(k[u][0], k[u][1])));
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (row[u] < 0) continue;                       // wave-uniform
+        const int i = row[u];
+        const bool a0 = v[u][0] && k[u][0] <= hi[u], a1 = v[u][1] && k[u][1] <= hi[u];
+        const unsigned long long e0 = __ballot(a0), e1 = __ballot(a1);
+        const int hits = __popcll(e0) + __popcll(e1);
+        unsigned bj = 0xffffu;
+        if (hits == 1) {
+            bj = e0 ? (unsigned)(__ffsll((long long)e0) - 1) : (unsigned)(64 + __ffsll((long long)e1) - 1);
+        } else if (hits > 1) {
+            double bk = INFINITY;
+            if (a0) { bk = small_exact_key(Ab, L, n, i, lane); bj = (unsigned)lane; }
+            if (a1) {
+                const double ke = small_exact_key(Ab, L, n, i, lane + 64);
+                if (better(ke, (unsigned)(lane + 64), bk, bj)) { bk = ke; bj = (unsigned)(lane + 64); }
+            }
+            wave_best(bk, bj);
+        }
+        if (lane == 0) {
+            L.key[i] = hits ? kf_at(L, i, (int)bj) : __builtin_nanf("");
+            L.cj[i] = (uint16_t)bj;
+        }
+    }
+}
+
+__device__ __forceinline__ void small_link(const SLds& L, int i, int j)
+{
+    const int oi = L.oend[i], oj = L.oend[j];
+    const int di = L.deg[i], dj = L.deg[j];
+    uint16_t* nb = reinterpret_cast<uint16_t*>(L.nbl);
+    nb[2 * i + di] = (uint16_t)j;
+    nb[2 * j + dj] = (uint16_t)i;
+    L.deg[i] = (uint8_t)(di + 1);
+    L.deg[j] = (uint8_t)(dj + 1);
+    if (di >= 1) L.key[i] = __builtin_nanf("");
+    if (dj >= 1) L.key[j] = __builtin_nanf("");
+    L.oend[oi] = (uint16_t)oj;
+    L.oend[oj] = (uint16_t)oi;
+}
+
+inline size_t greedy_small_lds(int n) { return (size_t)n * (size_t)(n - 1) * 2 + (size_t)n * 32 + 64; }
+
+template <typename H>
+__global__ void __launch_bounds__(256) k_greedy_small(const H* __restrict__ A, const double* __restrict__ points,
+                                                      int64_t* __restrict__ tours, int64_t num_maps, int n, int mpi,
+                                                      int prof)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float red_f[4];
+    __shared__ double red_e[4];
+    __shared__ unsigned red_i[4];
+    __shared__ int ctl[3];
+    const int64_t b = blockIdx.x;
+    if (b >= num_maps) return;
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = T >> 6;
+    SLds L;
+    L.n = n;
+    size_t off = 0;
+    L.px = reinterpret_cast<double*>(smem + off); off += sizeof(double) * (size_t)n;
+    L.py = reinterpret_cast<double*>(smem + off); off += sizeof(double) * (size_t)n;
+    L.Kf = reinterpret_cast<float*>(smem + off); off += sizeof(float) * ((size_t)n * (size_t)(n - 1) / 2);
+    L.key = reinterpret_cast<float*>(smem + off); off += sizeof(float) * (size_t)n;
+    L.nbl = reinterpret_cast<unsigned*>(smem + off); off += sizeof(unsigned) * (size_t)n;
+    L.cj = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n;
+    L.oend = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n;
+    L.queue = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n;
+    L.deg = reinterpret_cast<uint8_t*>(smem + off); off += (size_t)n;
+    L.flag = reinterpret_cast<uint8_t*>(smem + off);
+    const H* Ab = A + (size_t)b * (size_t)n * (size_t)n;
+    const double* P = points + (size_t)(b / mpi) * (size_t)n * 2;
+    const unsigned long long t_begin = prof ? clock64() : 0;
+    for (int i = tid; i < n; i += T) {
+        L.px[i] = P[2 * i];
+        L.py[i] = P[2 * i + 1];
+        L.oend[i] = (uint16_t)i;
+        L.deg[i] = 0;
+        L.flag[i] = 0;
+        L.nbl[i] = 0xffffffffu;
+        L.key[i] = 0.f;
+        L.queue[i] = (uint16_t)i;                        // round 0: every row is scanned
+    }
+    if (tid == 0) { ctl[0] = ctl[1] = 0; ctl[2] = n; }
+    __syncthreads();
+    // keys of all pairs i < j, stored both ways.  Rows r and n-2-r of the triangle hold n-1-r and r+1 pairs:
+    // together one line of n cells, so cell f of an (n/2) x n rectangle decodes with one division
+    const int lines = n >> 1, cells = lines * n;
+    const int mid = (n & 1) ? -1 : (n - 2) >> 1;        // n even: the middle row pairs with itself, once
+    for (int f0 = tid; f0 < cells; f0 += 2 * T) {
+        int pi[2], pj[2];
+        H sa[2], sb[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int f = f0 + u * T;
+            const int r = f / n, c = f - r * n;
+            int i = r, j = r + 1 + c;
+            if (c >= n - 1 - r) { i = n - 2 - r; j = i + 1 + (c - (n - 1 - r)); }
+            const bool in = f < cells && !(r == mid && c >= n - 1 - r);
+            pi[u] = in ? i : -1;
+            pj[u] = j;
+            sa[u] = in ? Ab[(size_t)i * n + j] : (H)0;
+            sb[u] = in ? Ab[(size_t)j * n + i] : (H)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (pi[u] < 0) continue;
+            const int i = pi[u], j = pj[u];
+            const H s2 = sa[u] + sb[u];                 // coo(i,j) + coo(j,i) in the heat map's dtype
+            const double dx = L.px[i] - L.px[j], dy = L.py[i] - L.py[j];
+            const float fx = (float)dx, fy = (float)dy;
+            const float d2 = fx * fx + fy * fy;
+            float k = -(float)s2 / sqrtf(d2);
+            if (!(d2 > 1.0e-30f) || !(fabsf(k) <= 3.0e38f) || !(fabsf((float)s2) <= 3.0e38f)) {
+                double ke = -(double)s2 / sqrt(dx * dx + dy * dy);
+                ke = ke != ke ? INFINITY : ke;
+                k = (float)ke;
+            }
+            kf_at(L, i, j) = k;
+        }
+    }
+    __syncthreads();
+
+    int merges = 0;
+    unsigned long long n_resc = 0, rounds = 0, serial_rounds = 0, t_adv = 0, t_resc = 0, t_apply = 0;
+    const unsigned long long t_fill = prof ? clock64() - t_begin : 0;
+    for (int guard = 0; merges < n - 1 && guard < n + 8; ++guard) {
+        // (1a) nodes whose candidate is no longer valid queue their row (round 0: all rows are queued)
+        const unsigned long long t0 = prof ? clock64() : 0;
+        if (tid == 0) ctl[0] = ctl[1] = 0;
+        if (guard > 0) {
+            for (int i = tid; i < n; i += T) {
+                const float k = L.key[i];
+                if (k != k) continue;
+                if (!small_ok(L, i, L.oend[i], L.cj[i])) L.queue[atomicAdd(&ctl[2], 1)] = (uint16_t)i;
+            }
+        }
+        __syncthreads();
+        // (1b) a wave per queued row
+        const unsigned long long t1 = prof ? clock64() : 0;
+        const int qn = ctl[2];
+        for (int q = wv; q < qn; q += 2 * nw)
+            small_rescan2(L, Ab, n, (int)L.queue[q], q + nw < qn ? (int)L.queue[q + nw] : -1, lane);
+        n_resc += (unsigned long long)qn;
+        __syncthreads();
+        // (2) choose
+        const unsigned long long t2 = prof ? clock64() : 0;
+        if (tid == 0) ctl[2] = 0;
+        int mine = 0;
+        bool any = false;
+        for (int i = tid; i < n; i += T) {
+            const float k = L.key[i];
+            if (k != k) continue;
+            any = true;
+            const int j = L.cj[i];
+            if (j < i || L.cj[j] != i) continue;
+            const float kj = L.key[j];
+            if (kj != kj) continue;
+            const int a = L.oend[i], c = L.oend[j];
+            const float hi = amb_hi(k);
+            if (a != i && L.key[a] <= hi) continue;     // NaN (no candidate) compares false: passes
+            if (c != j && L.key[c] <= hi) continue;
+            L.flag[i] = 1;
+            ++mine;
+        }
+        if (any) ctl[1] = 1;
+        if (mine) atomicAdd(&ctl[0], mine);
+        __syncthreads();
+        const int chosen = ctl[0];
+        if (!ctl[1]) break;
+        ++rounds;
+        if (chosen) {
+            for (int i = tid; i < n; i += T) {
+                if (L.flag[i]) {
+                    L.flag[i] = 0;
+                    small_link(L, i, L.cj[i]);
+                }
+            }
+            merges += chosen;
+        } else {
+            ++serial_rounds;
+            float lm = INFINITY;
+            for (int i = tid; i < n; i += T) {
+                const float k = L.key[i];
+                if (k == k) lm = fminf(lm, k);
+            }
+            lm = wave_min(lm);
+            if (lane == 0) red_f[wv] = lm;
+            __syncthreads();
+            float m = INFINITY;
+            for (int w = 0; w < nw; ++w) m = fminf(m, red_f[w]);
+            m = amb_hi(m);
+            double bk = INFINITY;
+            unsigned bf = 0xffffffffu;
+            for (int i = tid; i < n; i += T) {
+                if (!(L.key[i] <= m)) continue;
+                const unsigned cj = L.cj[i];
+                const unsigned f = (unsigned)i * (unsigned)n + cj;
+                const double key = small_exact_key(Ab, L, n, i, (int)cj);
+                if (better(key, f, bk, bf)) { bk = key; bf = f; }
+            }
+            wave_best(bk, bf);
+            if (lane == 0) { red_e[wv] = bk; red_i[wv] = bf; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 0; w < nw; ++w)
+                    if (better(red_e[w], red_i[w], bk, bf)) { bk = red_e[w]; bf = red_i[w]; }
+                if (bf != 0xffffffffu) {
+                    const int i = (int)(bf / (unsigned)n);
+                    small_link(L, i, (int)(bf - (unsigned)i * (unsigned)n));
+                }
+            }
+            ++merges;
+        }
+        __syncthreads();
+        if (prof) {
+            const unsigned long long t3 = clock64();
+            t_adv += t1 - t0; t_resc += t2 - t1; t_apply += t3 - t2;
+        }
+    }
+    __syncthreads();
+    if (prof && tid == 0) {
+        atomicAdd(&g_greedy_prof[0], t_adv + t_fill);       // key fill + validity checks
+        atomicAdd(&g_greedy_prof[1], t_resc);
+        atomicAdd(&g_greedy_prof[2], t_apply);
+        atomicAdd(&g_greedy_prof[3], (unsigned long long)merges);
+        atomicAdd(&g_greedy_prof[4], n_resc);
+        atomicAdd(&g_greedy_prof[5], clock64() - t_begin);
+        atomicAdd(&g_greedy_prof[6], rounds);
+        atomicAdd(&g_greedy_prof[7], serial_rounds);
+    }
+    if (tid >= 64) return;
+    // closing edge, then the walk (as in k_greedy)
+    int a = -1, c = -1;
+    for (int g = 0; g < ((n + 63) >> 6); ++g) {
+        const int k = (g << 6) + lane;
+        unsigned long long bal = __ballot(k < n && L.deg[k] < 2);
+        while (bal) {
+            const int k2 = (g << 6) + __ffsll((long long)bal) - 1;
+            bal &= bal - 1;
+            if (a < 0) a = k2; else c = k2;
+        }
+    }
+    if (lane == 0 && a >= 0 && c >= 0) {
+        uint16_t* nb = reinterpret_cast<uint16_t*>(L.nbl);
+        nb[2 * a + (nb[2 * a] != 0xffffu)] = (uint16_t)c;
+        nb[2 * c + (nb[2 * c] != 0xffffu)] = (uint16_t)a;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 2) {
+        int64_t* t = tours + (size_t)b * (size_t)(n + 1);
+        const int h = n >> 1, steps = lane == 0 ? h : n - 1 - h;
+        int prev = -1, cur = 0;
+        if (lane == 0) { t[0] = 0; t[n] = 0; }
+        for (int s2 = 1; s2 <= steps; ++s2) {
+            const unsigned w = L.nbl[cur];
+            const int n0 = (int)(w & 0xffffu), n1 = (int)(w >> 16);
+            int best = -1;
+            if (n0 != 0xffff && n0 != prev) best = n0;
+            if (n1 != 0xffff && n1 != prev && (s2 == 1 && lane == 1 ? (best < 0 || n1 < best) : n1 > best)) best = n1;
+            t[lane == 0 ? s2 : n - s2] = best;
+            prev = cur;
+            cur = best < 0 ? 0 : best;
+        }
+    }
+}
+
+int g_greedy_small_k1 = 1;              // diagnostic switch (tsp2opt_debug_greedy_cycles enable = 2 / 3): small maps on chip
+constexpr int kGreedyMaxN = 10200;      // partner indices are 16-bit, 12 B of LDS state per node
+
+// entries the prepare kernel extracts per node and the merge loop walks before it rescans a row: the row's
+// best only for small n, where tracking and extracting more costs the prepare kernel more than the loop gains
+inline int greedy_rounds(int n) { return kTopK; }
+
+inline size_t greedy_lds(int n) { return (size_t)n * 12 + 64; }
+
 struct GreedyWs {
-    size_t off_lkey, off_lj, total;     // key matrices at 0
+    size_t off_lkey, off_lj, off_nb, total;     // key matrices at 0
 };
 
 inline GreedyWs greedy_ws(int64_t num_maps, int n)
@@ -561,6 +872,7 @@ inline GreedyWs greedy_ws(int64_t num_maps, int n)
     size_t o = up((size_t)num_maps * (size_t)n * (size_t)n * 8);
     w.off_lkey = o; o += up((size_t)num_maps * (size_t)n * kTopK * 4);
     w.off_lj = o; o += up((size_t)num_maps * (size_t)n * kTopK * 2);
+    w.off_nb = o; o += up((size_t)num_maps * (size_t)n * 4);
     w.total = o + 256;
     return w;
 }
@@ -572,6 +884,15 @@ int greedy_t(const void* heat, const double* points, int64_t* tours, int64_t num
              void* ws, hipStream_t stream)
 {
     const H* A = static_cast<const H*>(heat);
+    if (n <= kGreedySmallN && g_greedy_small_k1) {       // everything on chip: no key matrix, no workspace
+        const size_t lds = greedy_small_lds(n);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_small<H>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_greedy_small<H>, dim3((unsigned)num_maps), dim3(n <= 64 ? 128 : 256), lds, stream, A, points,
+                           tours, num_maps, n, mpi, g_greedy_prof_on);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const GreedyWs wl = greedy_ws(num_maps, n);
     unsigned char* w8 = static_cast<unsigned char*>(ws);
     double* Kd = reinterpret_cast<double*>(w8);
@@ -586,13 +907,13 @@ int greedy_t(const void* heat, const double* points, int64_t* tours, int64_t num
             hipLaunchKernelGGL((k_greedy_prepare<H, 2>), grid, dim3(64, 8), 0, stream, A, points, Kd, lkey, lj, n, mpi, b0, greedy_rounds(n));
         HIP_TRY(hipGetLastError());
     }
+    uint16_t* nb = reinterpret_cast<uint16_t*>(w8 + wl.off_nb);
     const size_t lds = greedy_lds(n);
-    const bool big = greedy_k(n) == 0;
-    auto kern = n <= 512 ? k_greedy<8, 1> : big ? k_greedy<16, kGreedyBigWaves> : k_greedy<16, 1>;
+    auto kern = n <= 128 ? k_greedy<2> : n <= 256 ? k_greedy<4> : n <= 512 ? k_greedy<8> : k_greedy<0>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)num_maps), dim3(big ? 64 * kGreedyBigWaves : 64), lds, stream, Kd,
-                       lkey, lj, tours, num_maps, n, greedy_k(n), g_greedy_prof_on);
+    hipLaunchKernelGGL(kern, dim3((unsigned)num_maps), dim3(n <= 128 ? 64 : n <= 2048 ? 256 : 1024), lds, stream, Kd,
+                       lkey, lj, nb, tours, num_maps, n, greedy_rounds(n), g_greedy_prof_on);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -641,6 +962,7 @@ extern "C" int tsp2opt_debug_greedy_cycles(int32_t enable, int32_t device, uint6
     DeviceGuard guard(device);
     if (!guard.ok) return fail(TSP2OPT_E_HIP, "hipSetDevice failed");
     HIP_TRY(hipDeviceSynchronize());
+    if (enable == 2 || enable == 3) { g_greedy_small_k1 = enable == 2; return 0; }
     if (enable) {
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_greedy_prof), z, sizeof(z)));
