@@ -46,15 +46,61 @@
 
 namespace t2o {
 
-// A row's best partners in exact (key, j) order, from the two best entries every lane has seen among
-// its own columns (j = lane mod 64): lkey (fp32 rounding, NaN = no entry) and lj (0xffff = no entry).
-// Each round takes the best head over the wave (fp32 first, exact on fp32 ties) and the owner pops.
-// A lane that has popped both its entries no longer knows its next best, so the extraction stops
-// there: the list is then shorter than `rounds` but still an exact prefix of the row's order (the
-// merge loop falls back to a row rescan once a list is used up).
+// ---- fp32 filter keys ------------------------------------------------------------------------------------
+// Every pair's key is kept as an fp32 APPROXIMATION: the sum S in the heat map's dtype exactly as the
+// reference forms it, times the hardware reciprocal square root of the squared distance formed from the
+// double coordinate differences rounded to fp32 -- relative error below 2^-21, a fraction of the fp64 square
+// root and division it replaces.  The approximations only filter:
+// wherever a decision depends on two keys that are closer than kGreedyTol = 2^-18 relative (eight times the
+// error bound) the exact double keys are recomputed from the heat map (exact_key: the arithmetic of the
+// reference, cython_merge.pyx:23,37) and compared as (key, index).  Pairs whose fp32 evaluation leaves the
+// normal range (coincident points, overflow) store the fp32 rounding of the exact key, which is monotone.
+constexpr float kGreedyTol = 3.814697265625e-06f;        // 2^-18
+
+// the largest filter key that may still precede or tie one whose filter key is m
+__device__ __forceinline__ float amb_hi(float m)
+{
+    return fabsf(m) <= 3.0e38f ? m + fabsf(m) * kGreedyTol : m;
+}
+
+template <typename H>
+__device__ __forceinline__ float filter_key(H s, double dx, double dy)
+{
+    const float fx = (float)dx, fy = (float)dy;
+    const float d2 = fx * fx + fy * fy;
+    float k = -(float)s * __builtin_amdgcn_rsqf(d2);    // v_rsq_f32: 1 ulp on normal inputs
+    bool odd = !(d2 > 1.0e-30f) || !(fabsf(k) <= 3.0e38f);
+    if constexpr (sizeof(H) == 8) odd = odd || !(fabsf((float)s) <= 3.0e38f);
+    if (odd) {
+        double ke = -(double)s / sqrt(dx * dx + dy * dy);
+        ke = ke != ke ? INFINITY : ke;                  // NaN sorts last (numpy)
+        k = (float)ke;
+        if (k == 0.f && ke != 0.0) k = ke < 0.0 ? -1.0e-45f : 1.0e-45f;    // underflow: keep "zero" exact
+    }
+    if (k == 0.f && s != (H)0) k = s > (H)0 ? -1.0e-45f : 1.0e-45f;
+    return k;                                           // k == 0  <=>  the exact key is 0 (S == 0)
+}
+
+template <typename H>
+__device__ __forceinline__ double exact_key(const H* __restrict__ Ab, const double* __restrict__ P, int n, int i, int j)
+{
+    const H s = Ab[(size_t)i * n + j] + Ab[(size_t)j * n + i];
+    const double dx = P[2 * i] - P[2 * j], dy = P[2 * i + 1] - P[2 * j + 1];
+    const double k = -(double)s / sqrt(dx * dx + dy * dy);
+    return k != k ? INFINITY : k;
+}
+
+// A row's best partners in exact (key, j) order, from the two best entries (by filter key) every lane has
+// seen among its own columns (j = lane mod 64): lkey (filter key, NaN = no entry) and lj (0xffff = no entry).
+// Each round takes the best head over the wave if it is SEPARATED: no other head, and not the owner's second
+// entry, lies within the margin -- then it exactly precedes everything that is left in the row (a lane's
+// untracked entries are not better than its second).  The extraction stops at the first head that is not,
+// and where a lane has popped both its entries (its next best is unknown): the list is then shorter than
+// `rounds`, possibly empty, but always an exact prefix of the row's order; the merge loop rescans the row
+// once a list is used up.
 constexpr int kTopK = 4;
 
-__device__ __forceinline__ void row_topk(double k0, unsigned j0, double k1, unsigned j1, int lane, int rounds,
+__device__ __forceinline__ void row_topk(float k0, unsigned j0, float k1, unsigned j1, int lane, int rounds,
                                          float* __restrict__ lkey, uint16_t* __restrict__ lj)
 {
     int popped = 0;
@@ -62,26 +108,20 @@ __device__ __forceinline__ void row_topk(double k0, unsigned j0, double k1, unsi
 #pragma unroll 1
     for (; r < rounds; ++r) {
         if (__ballot(popped == 2)) break;               // somebody's next best is unknown
-        // an empty head (j = 0xffff) must lose against any real entry, also one whose key is +inf:
-        // compare the fp32 key AND the presence bit
         const bool has = j0 != 0xffffu;
-        const float hf = has ? (float)k0 : INFINITY;
+        const float hf = has ? k0 : INFINITY;
         const float m = wave_min(hf);
-        const unsigned long long bal = __ballot(has && hf == m);
-        if (!bal) break;                                // nothing left in this row
-        unsigned bj;
-        if (__popcll(bal) == 1) {
-            bj = (unsigned)__builtin_amdgcn_readlane((int)j0, __ffsll((long long)bal) - 1);
-        } else {                                        // fp32 tie: exact (key, j)
-            double bk = (has && hf == m) ? k0 : INFINITY;
-            bj = (has && hf == m) ? j0 : 0xffffffffu;
-            wave_best(bk, bj);
-        }
+        const float hi = amb_hi(m);
+        const bool in = has && hf <= hi;
+        const unsigned long long bal = __ballot(in);
+        if (__popcll(bal) != 1) break;                  // nothing left, or heads too close to call
+        if (__ballot(in && j1 != 0xffffu && k1 <= hi)) break;   // the owner's second entry is too close
+        const int src = __ffsll((long long)bal) - 1;
         if (lane == 0) {
             lkey[r] = m;
-            lj[r] = (uint16_t)bj;
+            lj[r] = (uint16_t)__builtin_amdgcn_readlane((int)j0, src);
         }
-        if (has && j0 == bj) {                          // the owner pops its head
+        if (lane == src) {                              // the owner pops its head
             k0 = k1; j0 = j1;
             k1 = INFINITY; j1 = 0xffffu;
             ++popped;
@@ -93,13 +133,12 @@ __device__ __forceinline__ void row_topk(double k0, unsigned j0, double k1, unsi
     }
 }
 
-// Kd[b][i][j] = key of edge (i, j) (+inf on the diagonal and for NaN, which numpy sorts last).
+// Kf[b][i][j] = filter key of edge (i, j) (+inf on the diagonal and for NaN, which numpy sorts last).
 // Block (64, 8): a band of 32 rows (4 per thread), column tiles of 64; the transposed operand goes
 // through LDS.
-// TK = entries tracked per lane and row (2, or 1 for small n where only the row's best is extracted)
-template <typename H, int TK>
+template <typename H>
 __global__ void __launch_bounds__(512) k_greedy_prepare(const H* __restrict__ A, const double* __restrict__ points,
-                                                        double* __restrict__ Kd, float* __restrict__ lkey,
+                                                        float* __restrict__ Kd, float* __restrict__ lkey,
                                                         uint16_t* __restrict__ lj, int n, int maps_per_instance,
                                                         int64_t map0, int topk_rounds)
 {
@@ -108,9 +147,10 @@ __global__ void __launch_bounds__(512) k_greedy_prepare(const H* __restrict__ A,
     const int x = threadIdx.x, y = threadIdx.y, t = y * 64 + x;
     const int i0 = blockIdx.x * 32;
     const H* Ab = A + (size_t)b * n * n;
-    double* Kb = Kd + (size_t)b * n * n;
+    float* Kb = Kd + (size_t)b * n * n;
     const double* P = points + (size_t)(b / maps_per_instance) * n * 2;
-    double rx[4], ry[4], b1k[4], b2k[4];                // b1/b2: this lane's two best (key, j) of the row
+    double rx[4], ry[4];
+    float b1k[4], b2k[4];                               // b1/b2: this lane's two best (filter key, j) of the row
     unsigned b1j[4], b2j[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -137,6 +177,7 @@ __global__ void __launch_bounds__(512) k_greedy_prepare(const H* __restrict__ A,
             tr[k] = (jr < n && ic < n) ? Ab[(size_t)jr * n + ic] : (H)0;
         }
     };
+    auto lessf = [](float k, unsigned j, float bk, unsigned bj) { return k < bk || (k == bk && j < bj); };
     load_tile(0);
     for (int c0 = 0; c0 < n; c0 += 64) {
         const int j = c0 + x;
@@ -152,16 +193,12 @@ __global__ void __launch_bounds__(512) k_greedy_prepare(const H* __restrict__ A,
         for (int rr = 0; rr < 4; ++rr) {
             const int r = y + 8 * rr, i = i0 + r;
             if (i < n && j < n) {
-                double k = INFINITY;
+                float k = INFINITY;
                 if (j != i) {
                     const H s = ac[rr] + tile[x][r];
-                    const double dx = rx[rr] - cx, dy = ry[rr] - cy;
-                    k = -(double)s / sqrt(dx * dx + dy * dy);
-                    k = k != k ? INFINITY : k;
-                    if constexpr (TK == 1) {
-                        if (better(k, (unsigned)j, b1k[rr], b1j[rr])) { b1k[rr] = k; b1j[rr] = (unsigned)j; }
-                    } else if (better(k, (unsigned)j, b2k[rr], b2j[rr])) {
-                        if (better(k, (unsigned)j, b1k[rr], b1j[rr])) {
+                    k = filter_key(s, rx[rr] - cx, ry[rr] - cy);
+                    if (lessf(k, (unsigned)j, b2k[rr], b2j[rr])) {
+                        if (lessf(k, (unsigned)j, b1k[rr], b1j[rr])) {
                             b2k[rr] = b1k[rr]; b2j[rr] = b1j[rr];
                             b1k[rr] = k; b1j[rr] = (unsigned)j;
                         } else {
@@ -206,66 +243,129 @@ __device__ __forceinline__ bool partner_ok(const RLds& L, int i, int oe, int j)
     return j != 0xffff && L.deg[j] < 2 && !(j == oe && oe != i);
 }
 
-// best valid partner of node i from its key row: minimum (key, j) over valid j.  One wave per row; the
-// row's keys are loaded unconditionally, 16 per lane in flight.
-__device__ __forceinline__ void rescan_store(const RLds& L, int i, int lane, double bk, unsigned bj)
+// ---- row rescans: best valid partner of node i from its row of filter keys, one wave per row ----------------
+// Every lane reports its best valid entry (k, j), whether it saw a second valid entry within the margin of the
+// row minimum is settled afterwards: if exactly one entry of the whole row lies within the margin it is the
+// exact best; otherwise the entries within the margin are compared exactly (a second pass over the row for
+// rows longer than the registers hold).
+template <typename H>
+struct RowCtx {
+    const float* Kb;        // this heat map's filter keys
+    const H* Ab;            // this heat map
+    const double* P;        // its instance's points
+    int n;
+};
+
+__device__ __forceinline__ void rescan_store(const RLds& L, int i, int lane, float fk, unsigned bj)
 {
-    wave_best(bk, bj);
     if (lane == 0) {
-        L.key[i] = bj == 0xffffu ? __builtin_nanf("") : (float)bk;
+        L.key[i] = bj == 0xffffu ? __builtin_nanf("") : fk;
         L.cj[i] = (uint16_t)bj;
     }
 }
 
-__device__ __forceinline__ void rescan_row(const RLds& L, const double* __restrict__ Kb, int n, int i, int lane)
+// exact decision among the valid entries of row i whose filter key is <= hi (all lanes)
+template <typename H>
+__device__ __forceinline__ void rescan_exact(const RLds& L, const RowCtx<H>& C, int i, int oe, float hi, int lane)
 {
-    constexpr int W = 16;
-    const double* Krow = Kb + (size_t)i * n;
-    const int oe = L.oend[i];
+    const float* Krow = C.Kb + (size_t)i * C.n;
     double bk = INFINITY;
     unsigned bj = 0xffffu;
+    for (int j = lane; j < C.n; j += 64) {
+        if (j == i || !partner_ok(L, i, oe, j) || !(Krow[j] <= hi)) continue;
+        const double k = exact_key(C.Ab, C.P, C.n, i, j);
+        if (k < bk || (k == bk && (unsigned)j < bj)) { bk = k; bj = (unsigned)j; }
+    }
+    wave_best(bk, bj);
+    rescan_store(L, i, lane, bj == 0xffffu ? 0.f : Krow[bj], bj);
+}
+
+// lane-local best (b1k, b1j) and the filter key of the lane's second best valid entry (b2k) -> the row's result
+template <typename H>
+__device__ __forceinline__ void rescan_finish(const RLds& L, const RowCtx<H>& C, int i, int oe, float b1k, unsigned b1j,
+                                              float b2k, int lane)
+{
+    const float m = wave_min(b1j != 0xffffu ? b1k : INFINITY);
+    const float hi = amb_hi(m);
+    const unsigned long long e1 = __ballot(b1j != 0xffffu && b1k <= hi);
+    const unsigned long long e2 = __ballot(b1j != 0xffffu && b2k <= hi);
+    if (!e1) { rescan_store(L, i, lane, 0.f, 0xffffu); return; }       // no valid partner at all
+    if (__popcll(e1) == 1 && !e2) {
+        const int src = __ffsll((long long)e1) - 1;
+        rescan_store(L, i, lane, m, (unsigned)__builtin_amdgcn_readlane((int)b1j, src));
+        return;
+    }
+    if (m == 0.f) {
+        // a zero filter key is an exactly zero key (filter_key): the tied entries are all equal, the lowest
+        // index wins -- every lane's best is its lowest column with the minimum (thresholded / densified
+        // sparse heat maps: most of a row)
+        unsigned jm = (b1j != 0xffffu && b1k == 0.f) ? b1j : 0xffffffffu;
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) jm = min(jm, (unsigned)__shfl_xor((int)jm, sft));
+        rescan_store(L, i, lane, m, jm);
+        return;
+    }
+    rescan_exact(L, C, i, oe, hi, lane);
+}
+
+__device__ __forceinline__ void lane_track(float k, unsigned j, float& b1k, unsigned& b1j, float& b2k)
+{
+    if (b1j == 0xffffu || k < b1k) { b2k = b1j == 0xffffu ? INFINITY : b1k; b1k = k; b1j = j; }
+    else if (k < b2k) b2k = k;                          // includes k == b1k: a second entry as good as the best
+}
+
+template <typename H>
+__device__ __forceinline__ void rescan_row(const RLds& L, const RowCtx<H>& C, int i, int lane)
+{
+    constexpr int W = 16;
+    const int n = C.n;
+    const float* Krow = C.Kb + (size_t)i * n;
+    const int oe = L.oend[i];
+    float b1k = INFINITY, b2k = INFINITY;
+    unsigned b1j = 0xffffu;
     for (int j0 = lane; j0 < n; j0 += 64 * W) {
-        double k[W];
+        float k[W];
 #pragma unroll
         for (int u = 0; u < W; ++u) k[u] = j0 + 64 * u < n ? Krow[j0 + 64 * u] : INFINITY;
 #pragma unroll
         for (int u = 0; u < W; ++u) {
             const int j = j0 + 64 * u;
             if (j >= n || j == i || !partner_ok(L, i, oe, j)) continue;
-            if (k[u] < bk || (k[u] == bk && (unsigned)j < bj)) { bk = k[u]; bj = (unsigned)j; }
+            lane_track(k[u], (unsigned)j, b1k, b1j, b2k);
         }
     }
-    rescan_store(L, i, lane, bk, bj);
+    rescan_finish(L, C, i, oe, b1k, b1j, b2k, lane);
 }
 
 // short rows (n <= 64 NL): the keys of 16 / NL queued rows are fetched in one global round trip, then every
 // row is reduced -- a rescan is a latency chain, and a workgroup has many of them per round
-template <int NL>
-__device__ __forceinline__ void rescan_rows(const RLds& L, const double* __restrict__ Kb, int n, int q0, int qn, int lane)
+template <typename H, int NL>
+__device__ __forceinline__ void rescan_rows(const RLds& L, const RowCtx<H>& C, int q0, int qn, int lane)
 {
     constexpr int R = 16 / NL;
+    const int n = C.n;
     int row[R];
-    double k[R][NL];
+    float k[R][NL];
 #pragma unroll
     for (int u = 0; u < R; ++u) row[u] = q0 + u < qn ? (int)L.queue[q0 + u] : -1;
 #pragma unroll
     for (int u = 0; u < R; ++u)
 #pragma unroll
         for (int v = 0; v < NL; ++v)
-            k[u][v] = (row[u] >= 0 && lane + 64 * v < n) ? Kb[(size_t)row[u] * n + lane + 64 * v] : INFINITY;
+            k[u][v] = (row[u] >= 0 && lane + 64 * v < n) ? C.Kb[(size_t)row[u] * n + lane + 64 * v] : INFINITY;
 #pragma unroll
     for (int u = 0; u < R; ++u) {
         if (row[u] < 0) continue;                       // wave-uniform
         const int i = row[u], oe = L.oend[i];
-        double bk = INFINITY;
-        unsigned bj = 0xffffu;
+        float b1k = INFINITY, b2k = INFINITY;
+        unsigned b1j = 0xffffu;
 #pragma unroll
         for (int v = 0; v < NL; ++v) {
             const int j = lane + 64 * v;
             if (j >= n || j == i || !partner_ok(L, i, oe, j)) continue;
-            if (k[u][v] < bk || (k[u][v] == bk && (unsigned)j < bj)) { bk = k[u][v]; bj = (unsigned)j; }
+            lane_track(k[u][v], (unsigned)j, b1k, b1j, b2k);
         }
-        rescan_store(L, i, lane, bk, bj);
+        rescan_finish(L, C, i, oe, b1k, b1j, b2k, lane);
     }
 }
 
@@ -289,18 +389,21 @@ __device__ __forceinline__ void link_nodes(const RLds& L, uint16_t* __restrict__
 // its short list (a thread per node, lists read where the prepare kernel left them), else a rescan of its
 // key row (queued; a wave per queued row).  An edge f = (i, j) is then inserted when
 //   * it is the candidate of both i and j -- no valid edge at i or j precedes it -- and
-//   * the far ends a, b of the two fragments it joins hold candidates with strictly larger fp32 keys:
+//   * the far ends a, b of the two fragments it joins hold candidates whose filter keys are larger by more
+//     than the margin (so their exact keys are strictly larger):
 //     nothing can happen at i, j, a or b before f's turn in the sorted scan, so f is valid at its turn, and
 //     the only edge whose validity f changes, (a, b), comes after it.
 // Edges chosen in one round join disjoint pairs of fragments: a thread each applies them.  The valid edge
-// with the globally smallest key always qualifies unless another candidate shares its fp32 key; a round
-// that finds nothing inserts exactly that edge after comparing the tied candidates exactly (double key from
-// the key matrix, then flat index): the serial rule.  A few tens of rounds replace about 3N serial steps.
+// with the globally smallest key always qualifies unless another candidate's filter key lies within the
+// margin; a round that finds nothing inserts exactly that edge after comparing those candidates exactly
+// (double key, then flat index): the serial rule.  A few tens of rounds replace about 3N serial steps.
 // NL: key loads per lane that cover a row (2, 4, 8 for n <= 128, 256, 512), 0 = longer rows
-template <int NL>
-__global__ void __launch_bounds__(1024) k_greedy(const double* __restrict__ Kd, const float* __restrict__ lkey,
+template <typename H, int NL>
+__global__ void __launch_bounds__(1024) k_greedy(const float* __restrict__ Kd, const H* __restrict__ A,
+                                                 const double* __restrict__ points, const float* __restrict__ lkey,
                                                  const uint16_t* __restrict__ lj0, uint16_t* __restrict__ nbg,
-                                                 int64_t* __restrict__ tours, int64_t num_maps, int n, int K, int prof)
+                                                 int64_t* __restrict__ tours, int64_t num_maps, int n, int mpi, int K,
+                                                 int prof)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red_f[16];
@@ -319,17 +422,20 @@ __global__ void __launch_bounds__(1024) k_greedy(const double* __restrict__ Kd, 
     L.queue = reinterpret_cast<uint16_t*>(smem + off); off += sizeof(uint16_t) * (size_t)n;
     L.deg = reinterpret_cast<uint8_t*>(smem + off); off += (size_t)n;
     L.lp = reinterpret_cast<uint8_t*>(smem + off);
-    const double* Kb = Kd + (size_t)b * (size_t)n * (size_t)n;
+    const RowCtx<H> C{Kd + (size_t)b * (size_t)n * (size_t)n, A + (size_t)b * (size_t)n * (size_t)n,
+                      points + (size_t)(b / mpi) * (size_t)n * 2, n};
     const float* glk = lkey + (size_t)b * (size_t)n * kTopK;
     const uint16_t* glj = lj0 + (size_t)b * (size_t)n * kTopK;
     uint16_t* nb = nbg + (size_t)b * 2 * (size_t)n;
     for (int i = tid; i < n; i += T) {
         L.oend[i] = (uint16_t)i;
         L.deg[i] = 0;
-        L.lp[i] = 0;
         nb[2 * i] = nb[2 * i + 1] = 0xffffu;
-        L.key[i] = glk[(size_t)i * kTopK];              // first candidates: the heads of the lists
-        L.cj[i] = glj[(size_t)i * kTopK];
+        const float hk = glk[(size_t)i * kTopK];        // first candidates: the heads of the lists; an empty
+        const unsigned hj = glj[(size_t)i * kTopK];     // list (the row's best was too close to call) makes the
+        L.lp[i] = hj == 0xffffu ? (uint8_t)kTopK : (uint8_t)0;     // first round rescan the row
+        L.key[i] = hj == 0xffffu ? 0.f : hk;
+        L.cj[i] = (uint16_t)hj;
     }
     if (tid == 0) ctl[0] = ctl[1] = ctl[2] = 0;
     __syncthreads();
@@ -373,9 +479,9 @@ __global__ void __launch_bounds__(1024) k_greedy(const double* __restrict__ Kd, 
         // (1b) queued rows: a wave each
         const int qn = ctl[2];
         if constexpr (NL > 0) {
-            for (int q0 = wv * (16 / NL); q0 < qn; q0 += nw * (16 / NL)) rescan_rows<NL>(L, Kb, n, q0, qn, lane);
+            for (int q0 = wv * (16 / NL); q0 < qn; q0 += nw * (16 / NL)) rescan_rows<H, NL>(L, C, q0, qn, lane);
         } else {
-            for (int q = wv; q < qn; q += nw) rescan_row(L, Kb, n, L.queue[q], lane);
+            for (int q = wv; q < qn; q += nw) rescan_row(L, C, (int)L.queue[q], lane);
         }
         n_resc += (unsigned long long)qn;
         __syncthreads();
@@ -393,8 +499,9 @@ __global__ void __launch_bounds__(1024) k_greedy(const double* __restrict__ Kd, 
             const float kj = L.key[j];
             if (kj != kj) continue;
             const int a = L.oend[i], c = L.oend[j];
-            if (a != i && L.key[a] <= k) continue;      // NaN (no candidate) compares false: passes
-            if (c != j && L.key[c] <= k) continue;
+            const float hi = amb_hi(k);
+            if (a != i && L.key[a] <= hi) continue;     // NaN (no candidate) compares false: passes
+            if (c != j && L.key[c] <= hi) continue;
             L.lp[i] |= 0x80u;
             ++mine;
         }
@@ -415,7 +522,7 @@ __global__ void __launch_bounds__(1024) k_greedy(const double* __restrict__ Kd, 
             }
             merges += chosen;
         } else {
-            // different edges share the smallest fp32 key: exact keys from the key matrix, then the flat index
+            // different edges within the margin of the smallest filter key: exact keys, then the flat index
             ++serial_rounds;
             float lm = INFINITY;
             for (int i = tid; i < n; i += T) {
@@ -427,12 +534,14 @@ __global__ void __launch_bounds__(1024) k_greedy(const double* __restrict__ Kd, 
             __syncthreads();
             float m = INFINITY;
             for (int w = 0; w < nw; ++w) m = fminf(m, red_f[w]);
+            m = amb_hi(m);
             double bk = INFINITY;
             unsigned bf = 0xffffffffu;
             for (int i = tid; i < n; i += T) {
-                if (!(L.key[i] == m)) continue;
-                const unsigned f = (unsigned)i * (unsigned)n + L.cj[i];
-                const double key = Kb[f];
+                if (!(L.key[i] <= m)) continue;
+                const unsigned cj = L.cj[i];
+                const unsigned f = (unsigned)i * (unsigned)n + cj;
+                const double key = exact_key(C.Ab, C.P, n, i, (int)cj);
                 if (better(key, f, bk, bf)) { bk = key; bf = f; }
             }
             wave_best(bk, bf);
@@ -512,22 +621,10 @@ __global__ void __launch_bounds__(1024) k_greedy(const double* __restrict__ Kd, 
 }
 
 // ---- small heat maps (n <= kGreedySmallN): one kernel, everything on chip -------------------------------
-// fp32 APPROXIMATIONS of a heat map's n^2 keys fit the LDS (40 KB at n = 100), so no key matrix goes to
-// memory: the workgroup reads its heat map once, keeps an fp32 key for every pair (the sum S in the heat
-// map's dtype as the reference forms it, the distance from the double coordinate differences rounded to
-// fp32: relative error below 2^-21), and runs the same rounds with row rescans out of LDS.  The fp32 keys
-// are only a filter with a margin: wherever a decision depends on two keys that are closer than 2^-19
-// relative (kGreedyTol, four times the error bound), the exact double keys are recomputed from the heat map
-// with the arithmetic of k_greedy_prepare and compared as (key, index).  Pairs whose fp32 evaluation leaves
-// the normal range (coincident points, overflow) get the fp32 rounding of the exact key, which is monotone.
+// The filter keys of a heat map's n (n - 1) / 2 pairs fit the LDS (20 KB at n = 100), so no key matrix goes
+// to memory: the workgroup reads its heat map once, keeps the filter key of every pair, and runs the same
+// rounds with row rescans out of LDS (margins and exact comparisons as described at kGreedyTol).
 constexpr int kGreedySmallN = 128;
-constexpr float kGreedyTol = 1.9073486328125e-06f;      // 2^-19
-
-// the largest key that may still precede or tie one whose fp32 value is m
-__device__ __forceinline__ float amb_hi(float m)
-{
-    return fabsf(m) <= 3.0e38f ? m + fabsf(m) * kGreedyTol : m;
-}
 
 struct SLds {
     float* Kf;              // the n (n - 1) / 2 keys of the pairs i < j, row-major triangle (see kf_at)
@@ -695,14 +792,7 @@ __global__ void __launch_bounds__(256) k_greedy_small(const H* __restrict__ A, c
             const int i = pi[u], j = pj[u];
             const H s2 = sa[u] + sb[u];                 // coo(i,j) + coo(j,i) in the heat map's dtype
             const double dx = L.px[i] - L.px[j], dy = L.py[i] - L.py[j];
-            const float fx = (float)dx, fy = (float)dy;
-            const float d2 = fx * fx + fy * fy;
-            float k = -(float)s2 / sqrtf(d2);
-            if (!(d2 > 1.0e-30f) || !(fabsf(k) <= 3.0e38f) || !(fabsf((float)s2) <= 3.0e38f)) {
-                double ke = -(double)s2 / sqrt(dx * dx + dy * dy);
-                ke = ke != ke ? INFINITY : ke;
-                k = (float)ke;
-            }
+            const float k = filter_key(s2, dx, dy);
             kf_at(L, i, j) = k;
         }
     }
@@ -869,7 +959,7 @@ inline GreedyWs greedy_ws(int64_t num_maps, int n)
 {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     GreedyWs w{};
-    size_t o = up((size_t)num_maps * (size_t)n * (size_t)n * 8);
+    size_t o = up((size_t)num_maps * (size_t)n * (size_t)n * 4);
     w.off_lkey = o; o += up((size_t)num_maps * (size_t)n * kTopK * 4);
     w.off_lj = o; o += up((size_t)num_maps * (size_t)n * kTopK * 2);
     w.off_nb = o; o += up((size_t)num_maps * (size_t)n * 4);
@@ -895,25 +985,22 @@ int greedy_t(const void* heat, const double* points, int64_t* tours, int64_t num
     }
     const GreedyWs wl = greedy_ws(num_maps, n);
     unsigned char* w8 = static_cast<unsigned char*>(ws);
-    double* Kd = reinterpret_cast<double*>(w8);
+    float* Kd = reinterpret_cast<float*>(w8);
     float* lkey = reinterpret_cast<float*>(w8 + wl.off_lkey);
     uint16_t* lj = reinterpret_cast<uint16_t*>(w8 + wl.off_lj);
     // grid.y is limited to 65535: prepare in slabs of heat maps
     for (int64_t b0 = 0; b0 < num_maps; b0 += 32768) {
         const dim3 grid((unsigned)((n + 31) / 32), (unsigned)std::min<int64_t>(32768, num_maps - b0), 1);
-        if (greedy_rounds(n) == 1)
-            hipLaunchKernelGGL((k_greedy_prepare<H, 1>), grid, dim3(64, 8), 0, stream, A, points, Kd, lkey, lj, n, mpi, b0, 1);
-        else
-            hipLaunchKernelGGL((k_greedy_prepare<H, 2>), grid, dim3(64, 8), 0, stream, A, points, Kd, lkey, lj, n, mpi, b0, greedy_rounds(n));
+        hipLaunchKernelGGL((k_greedy_prepare<H>), grid, dim3(64, 8), 0, stream, A, points, Kd, lkey, lj, n, mpi, b0, greedy_rounds(n));
         HIP_TRY(hipGetLastError());
     }
     uint16_t* nb = reinterpret_cast<uint16_t*>(w8 + wl.off_nb);
     const size_t lds = greedy_lds(n);
-    auto kern = n <= 128 ? k_greedy<2> : n <= 256 ? k_greedy<4> : n <= 512 ? k_greedy<8> : k_greedy<0>;
+    auto kern = n <= 128 ? k_greedy<H, 2> : n <= 256 ? k_greedy<H, 4> : n <= 512 ? k_greedy<H, 8> : k_greedy<H, 0>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)num_maps), dim3(n <= 128 ? 64 : n <= 2048 ? 256 : 1024), lds, stream, Kd,
-                       lkey, lj, nb, tours, num_maps, n, greedy_rounds(n), g_greedy_prof_on);
+                       A, points, lkey, lj, nb, tours, num_maps, n, mpi, greedy_rounds(n), g_greedy_prof_on);
     HIP_TRY(hipGetLastError());
     return 0;
 }
