@@ -1,10 +1,11 @@
 #!/bin/bash
 # tools/profile_round.sh TAG [stage ...] -- evidence for profiles/: bench lines, rocprofv3 kernel
-# stats, PMC passes, phase breakdowns.  Stages: bench kt pmc configs variants phases dist (default all).
+# stats, PMC passes, phase breakdowns.  Stages: bench kt pmc configs ktconfigs variants phases dist strong
+# pipeline lsops (default all).
 # Everything lands in gpurun_out/TAG_*.  Run on the GPU box from the repo root.
 set -u
 TAG=${1:-rXX}; shift || true
-STAGES=${*:-bench kt pmc configs variants phases dist strong}
+STAGES=${*:-bench kt pmc configs ktconfigs variants phases dist strong pipeline lsops}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out
 for st in $STAGES; do
@@ -14,11 +15,25 @@ for st in $STAGES; do
   kt) timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -- python bench.py --steps 4 --warmup 1 --no-cpu > $O/${TAG}_kt.log 2>&1 || exit 1
       cp $(find $O/${TAG}_kt -name '*kernel_stats.csv' | head -1) $O/${TAG}_kernel_stats.csv ;;
   pmc) bash tools/pmc_passes.sh || exit 1
-       python tools/summarize_pmc.py > $O/${TAG}_pmc_summary.json || exit 1 ;;
+       python tools/summarize_pmc.py > $O/${TAG}_tsp500_pmc_summary.json || exit 1 ;;
   configs) for c in tsp50 tsp100 tsp1000 tsp10000; do
       echo "   bench $c"
       timeout -k 10 250 python bench.py --config $c --steps 3 --warmup 1 > $O/${TAG}_bench_$c.json 2> $O/${TAG}_bench_$c.err || exit 1
     done ;;
+  ktconfigs) for c in tsp100 tsp1000 tsp10000; do
+      echo "   kernel trace $c"
+      timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${TAG}_kt_$c -- python bench.py --config $c --steps 2 --warmup 1 --no-cpu > $O/${TAG}_kt_$c.log 2>&1 || exit 1
+      cp $(find /tmp/${TAG}_kt_$c -name '*kernel_stats.csv' | head -1) $O/${TAG}_kernel_stats_$c.csv
+    done ;;
+  pipeline) for c in tsp50 tsp100 tsp500; do
+      echo "   pipeline $c (dense heat maps)"
+      timeout -k 10 250 python tools/pipeline_bench.py --config $c --steps 5 > $O/${TAG}_pipeline_$c.json 2> $O/${TAG}_pipeline_$c.err || exit 1
+    done
+    for c in tsp1000 tsp10000; do
+      echo "   pipeline $c (k = 50 lists)"
+      timeout -k 10 250 python tools/pipeline_bench.py --config $c --knn 50 --sparse --steps 5 --check 1 > $O/${TAG}_pipeline_sparse_$c.json 2> $O/${TAG}_pipeline_sparse_$c.err || exit 1
+    done ;;
+  lsops) timeout -k 10 250 python tools/ls_bench.py > $O/${TAG}_ls_ops_bench.txt 2>&1 || exit 1 ;;
   variants) timeout -k 10 200 python bench.py --mode grouped --no-cpu > $O/${TAG}_bench_tsp500_grouped.json 2> $O/${TAG}_bench_tsp500_grouped.err || exit 1
       timeout -k 10 200 python bench.py --dtype f32 --no-cpu > $O/${TAG}_bench_tsp500_f32.json 2> $O/${TAG}_bench_tsp500_f32.err || exit 1 ;;
   phases) # the phase timers only exist in the diagnostic build (python -m ml4tspbench_amd.build --fine)
