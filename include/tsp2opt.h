@@ -238,7 +238,8 @@ int tsp2opt_plan(int32_t n, int32_t dtype, int32_t device, int32_t* out7);
  * enable = 1 zeroes and switches them on for `device`; enable = 0 switches them off and copies
  * out8 = {list-advance cycles, row-rescan cycles, choose+apply cycles, merges, rescans, loop cycles, rounds,
  * rounds that inserted one exactly compared edge} summed over the heat maps decoded in between.
- * Synchronises the device. */
+ * Synchronises the device.  enable = 3 / 2: decode heat maps of <= 128 nodes with the general kernels instead of
+ * the on-chip one / back to the default (for A/B runs).  The switches belong to the calling thread. */
 int tsp2opt_debug_greedy_cycles(int32_t enable, int32_t device, uint64_t* out8);
 
 /*

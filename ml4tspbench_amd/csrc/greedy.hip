@@ -606,7 +606,7 @@ __global__ void __launch_bounds__(1024) k_greedy(const float* __restrict__ Kd, c
         int64_t* t = tours + (size_t)b * (size_t)(n + 1);
         const int h = n >> 1, steps = lane == 0 ? h : n - 1 - h;
         int prev = -1, cur = 0;
-        if (lane == 0) { t[0] = 0; t[n] = 0; }
+        if (lane == 0) { t[0] = 0; t[n] = n == 2 ? -1 : 0; }   // n = 2: the reference's walk has no step left (it raises); -1 like the oracle
         for (int s2 = 1; s2 <= steps; ++s2) {
             const unsigned w = nbl[cur];
             const int n0 = (int)(w & 0xffffu), n1 = (int)(w >> 16);
@@ -928,7 +928,7 @@ __global__ void __launch_bounds__(256) k_greedy_small(const H* __restrict__ A, c
         int64_t* t = tours + (size_t)b * (size_t)(n + 1);
         const int h = n >> 1, steps = lane == 0 ? h : n - 1 - h;
         int prev = -1, cur = 0;
-        if (lane == 0) { t[0] = 0; t[n] = 0; }
+        if (lane == 0) { t[0] = 0; t[n] = n == 2 ? -1 : 0; }   // n = 2: the reference's walk has no step left (it raises); -1 like the oracle
         for (int s2 = 1; s2 <= steps; ++s2) {
             const unsigned w = L.nbl[cur];
             const int n0 = (int)(w & 0xffffu), n1 = (int)(w >> 16);
@@ -942,7 +942,8 @@ __global__ void __launch_bounds__(256) k_greedy_small(const H* __restrict__ A, c
     }
 }
 
-int g_greedy_small_k1 = 1;              // diagnostic switch (tsp2opt_debug_greedy_cycles enable = 2 / 3): small maps on chip
+// diagnostic switches belong to the calling thread, like the 2-opt knobs (tsp2opt.hip: thread_local Opts)
+thread_local int g_greedy_small_k1 = 1; // tsp2opt_debug_greedy_cycles enable = 2 / 3: small maps on chip or not
 constexpr int kGreedyMaxN = 10200;      // partner indices are 16-bit, 12 B of LDS state per node
 
 // entries the prepare kernel extracts per node and the merge loop walks before it rescans a row: the row's
@@ -967,7 +968,7 @@ inline GreedyWs greedy_ws(int64_t num_maps, int n)
     return w;
 }
 
-int g_greedy_prof_on = 0;
+thread_local int g_greedy_prof_on = 0;
 
 template <typename H>
 int greedy_t(const void* heat, const double* points, int64_t* tours, int64_t num_maps, int n, int mpi,

@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(1024) k_greedy_sparse(const uint16_t* __restri
         int64_t* t = tours + (size_t)b * (size_t)(n + 1);
         const int h = n >> 1, steps = lane == 0 ? h : n - 1 - h;
         int prev = -1, cur = 0;
-        if (lane == 0) { t[0] = 0; t[n] = 0; }
+        if (lane == 0) { t[0] = 0; t[n] = n == 2 ? -1 : 0; }   // n = 2: the reference's walk has no step left (it raises); -1 like the oracle
         for (int s2 = 1; s2 <= steps; ++s2) {
             const unsigned w = nbl[cur];
             const int n0 = (int)(w & 0xffffu), n1 = (int)(w >> 16);

@@ -139,6 +139,41 @@ def test_gpu_greedy_near_ties_are_decided_exactly(n, dtype, eps):
 
 
 @pytest.mark.gpu
+def test_gpu_greedy_small_maps_through_the_general_kernels():
+    """Heat maps of <= 128 nodes normally take the on-chip kernel; the diagnostic switch sends them through
+    prepare + merge rounds (short rows, 8 rows in flight per wave): same tours."""
+    import ctypes
+    from ml4tspbench_amd import greedy_decode_device, _lib
+    from oracle import greedy_oracle
+    L = _lib.lib()
+    L.tsp2opt_debug_greedy_cycles.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    dev = torch.device("cuda", 0)
+    try:
+        assert L.tsp2opt_debug_greedy_cycles(3, 0, None) == 0
+        for n, dtype in ((2, np.float32), (3, np.float64), (50, np.float32), (100, np.float64), (128, np.float32)):
+            rng = np.random.default_rng(n)
+            pts = rng.random((2, n, 2))
+            heat = rng.random((4, n, n)).astype(dtype)
+            heat[1][rng.random((n, n)) < 0.7] = 0          # mostly zeros: index-ordered ties
+            got = greedy_decode_device(torch.from_numpy(heat).to(dev), torch.from_numpy(pts).to(dev),
+                                       maps_per_instance=2).cpu().numpy()
+            for k in range(4):
+                assert np.array_equal(got[k], greedy_oracle.greedy(pts[k // 2], heat[k])[0]), (n, k)
+    finally:
+        L.tsp2opt_debug_greedy_cycles(2, 0, None)
+    # and the default path on the same kind of input
+    n = 100
+    rng = np.random.default_rng(n)
+    pts = rng.random((2, n, 2))
+    heat = rng.random((4, n, n)).astype(np.float64)
+    heat[1][rng.random((n, n)) < 0.7] = 0
+    got = greedy_decode_device(torch.from_numpy(heat).to(dev), torch.from_numpy(pts).to(dev),
+                               maps_per_instance=2).cpu().numpy()
+    for k in range(4):
+        assert np.array_equal(got[k], greedy_oracle.greedy(pts[k // 2], heat[k])[0]), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["dense", "sparse", "ties", "grid"])
 def test_gpu_greedy_grid_of_n(kind):
     """A grid of N (list lengths, scan widths, row tails) x map kinds, both dtypes, against the oracle."""
