@@ -42,6 +42,7 @@ struct LsParams {
     int op;                 // 0 two-opt, 1 relocate, 2 local_search loop
     int max_rounds;
     int xlds;               // coordinates in LDS
+    int flat;               // edge-weight tables in LDS: candidates of a full scan are spread over all lanes
 };
 
 struct LsCtx {
@@ -50,6 +51,9 @@ struct LsCtx {
     const double* pen;      // penalty matrix of this tour or null
     double k;
     int n;
+    double* ewf;            // flat scans: ewf[p] = w(t[p-1], t[p]), ewr[p] = w(t[p], t[p-1]), p = 1 .. n, and
+    double* ewr;            // head[i] = (-w(a,b) - w(b,c)) + w(a,c) of relocate's node i; null: rows per lane
+    double* head;
 };
 
 template <bool G>
@@ -103,7 +107,52 @@ __device__ void ls_best(const LsCtx& c, int op, int fixed, int tid, int nt, doub
             consider(delta, i, j);
         }
     };
-    if (fixed >= 0) {                           // one row, the lanes share its columns (ascending per lane)
+    if (fixed < 0 && c.ewf) {
+        // Full scan, flat: every candidate costs two square roots -- the weights of the tour's own edges (and
+        // relocate's three per node) are tabulated once per scan, bit-identical to recomputing them -- and the
+        // candidates are spread evenly over the lanes.  The reference's "first strict improvement in scan
+        // order" is the lexicographic minimum of (delta, i n + j) over the admissible candidates.
+        const int m = n - 1;                            // positions 1 .. m take part
+        auto consider_any = [&](double delta, int i, int j) {
+            const unsigned kk = (unsigned)i * (unsigned)n + (unsigned)j;
+            if (delta < 0.0 && !is_close0(delta) && better(delta, kk, e, key)) { e = delta; key = kk; }
+        };
+        __syncthreads();                                // the tour may just have been rewritten
+        if (op == 0) {
+            for (int q = 1 + tid; q <= n; q += nt) c.ewr[q] = wgt<G>(c, c.t[q], c.t[q - 1]);
+            __syncthreads();
+            // pairs u < v of M = m - 1 items (i = u + 1, j = v + 2): rows r and M-2-r of the triangle share a
+            // line of M cells
+            const int M = m - 1, lines = M > 1 ? M >> 1 : 0, cells = lines * M;
+            const int mid = (M & 1) ? -1 : (M - 2) >> 1;
+            for (int f = tid; f < cells; f += nt) {
+                const int r = f / M, cc0 = f - r * M;
+                int u = r, v = r + 1 + cc0;
+                if (cc0 >= M - 1 - r) {
+                    if (r == mid) continue;
+                    u = M - 2 - r;
+                    v = u + 1 + (cc0 - (M - 1 - r));
+                }
+                const int lo = u + 1, hi = v + 2;
+                const int a = c.t[lo], b = c.t[lo - 1], cc = c.t[hi], dd = c.t[hi - 1];
+                consider_any(((wgt<G>(c, a, cc) + wgt<G>(c, b, dd)) + c.ewr[lo]) - c.ewr[hi], lo, hi);
+            }
+        } else {
+            for (int q = 1 + tid; q <= n; q += nt) c.ewf[q] = wgt<G>(c, c.t[q - 1], c.t[q]);
+            __syncthreads();
+            for (int i = 1 + tid; i <= m; i += nt)
+                c.head[i] = (-c.ewf[i] - c.ewf[i + 1]) + wgt<G>(c, c.t[i - 1], c.t[i + 1]);
+            __syncthreads();
+            for (int f = tid; f < m * m; f += nt) {
+                const int i = f / m + 1, j = f - (i - 1) * m + 1;
+                if (j == i || i - j == 1) continue;
+                const int b = c.t[i];
+                const int d = i < j ? c.t[j] : c.t[j - 1], ee = i < j ? c.t[j + 1] : c.t[j];
+                const double wde = i < j ? c.ewf[j + 1] : c.ewf[j];
+                consider_any(((c.head[i] - wde) + wgt<G>(c, d, b)) + wgt<G>(c, b, ee), i, j);
+            }
+        }
+    } else if (fixed >= 0) {                    // one row, the lanes share its columns (ascending per lane)
         if (fixed >= 1 && fixed <= n - 1) {
             if (op == 0) row_two_opt(fixed, 1 + tid, nt);
             else row_relocate(fixed, 1 + tid, nt, false);
@@ -199,6 +248,13 @@ __global__ void __launch_bounds__(256) k_ls(LsParams p)
     c.pen = G ? p.penalty + (size_t)tk * (size_t)n * (size_t)n : nullptr;
     c.k = G ? p.guide_k[tk] : 0.0;
     c.n = n;
+    c.ewf = c.ewr = c.head = nullptr;
+    if (p.flat) {
+        double* tab = xl + 2 * (size_t)n;
+        c.ewf = tab;
+        c.ewr = tab + (n + 2);
+        c.head = tab + 2 * (size_t)(n + 2);
+    }
     double e;
     unsigned key;
     int rounds = 0;
@@ -240,6 +296,8 @@ int ls_launch(LsParams p, int device, hipStream_t stream)
     size_t lds = base;
     p.xlds = 0;
     if (base + 16 * (size_t)p.n <= 160 * 1024) { p.xlds = 1; lds += 16 * (size_t)p.n; }
+    p.flat = 0;
+    if (p.xlds && lds + 24 * (size_t)(p.n + 2) <= 64 * 1024) { p.flat = 1; lds += 24 * (size_t)(p.n + 2); }
     if (lds > 160 * 1024) return fail(TSP2OPT_E_UNSUPPORTED, "n too large for the local-search operators");
     const bool guided = p.guide_k != nullptr;
     auto kern = guided ? k_ls<true> : k_ls<false>;
