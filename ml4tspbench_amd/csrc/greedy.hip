@@ -13,24 +13,22 @@
 // can disturb any more are inserted together, many per round (see k_greedy): a few tens of rounds of
 // parallel work instead of an N^2 log N sort or 3N serial steps.
 //
-// Two kernels.  k_greedy_prepare (fully parallel) turns every heat map into the matrix of edge
-// keys, S = A + A^T formed on the fly through a tiled transpose so that A and A^T are both read
-// coalesced, and extracts every node's (up to) kTopK best partners in exact (key, index) order from the
-// two best entries each lane saw in its own columns.  k_greedy runs the merge rounds, one workgroup per
-// heat map with 12 B of LDS state per node: the fp32 rounding of each node's candidate key and its partner,
-// a cursor into the node's short list, degree, the other endpoint of each fragment, and the queue of rows
-// to rescan.  An invalidated candidate is replaced by the next still-valid entry of the node's list
-// (validity only decays, so skipped entries never come back) and by a rescan of the node's key row once
-// the list is used up.
+// General path, two kernels.  k_greedy_prepare (fully parallel) turns every heat map into the matrix of
+// fp32 filter keys (below), S = A + A^T formed on the fly through a tiled transpose so that A and A^T are
+// both read coalesced, and extracts every node's (up to) kTopK best partners as an exact prefix of the
+// row's (key, index) order.  k_greedy runs the merge rounds, one workgroup per heat map with 12 B of LDS
+// state per node: each node's candidate (filter key, partner), a cursor into its short list, degree, the
+// other endpoint of each fragment, and the queue of rows to rescan.  An invalidated candidate is replaced by
+// the next still-valid entry of the node's list (validity only decays, so skipped entries never come back)
+// and by a rescan of the node's key row once the list is used up.  Heat maps of <= 128 nodes take
+// k_greedy_small instead: one kernel with the filter keys of all pairs in LDS.
 //
 // Arithmetic follows the reference: S is summed in the heat map's dtype (numpy adds float32 arrays
 // in float32, greedy_search.py:36-38), keys are -double(S)/sqrt(dx*dx+dy*dy) in double
-// (cython_merge.pyx:23,37).  The per-step choice among the nodes' candidates first compares the
-// fp32 ROUNDINGS of the keys, which is monotone: the exact minimum is among the entries equal to
-// the fp32 minimum, and only those are compared in double (fetched from the key matrix; the common
-// tie, two nodes naming each other, is the same edge and needs no fetch).  Where two different edges have
-// exactly equal keys the reference's order is numpy's unstable argsort order; here (and in the
-// oracle) the lower flat index wins.
+// (cython_merge.pyx:23,37) -- wherever two keys are close enough for the difference to matter; everything
+// else is decided on fp32 approximations with a proven error bound (see "fp32 filter keys").  Where two
+// different edges have exactly equal keys the reference's order is numpy's unstable argsort order; here
+// (and in the oracle) the lower flat index wins.
 
 #include <hip/hip_runtime.h>
 
@@ -943,7 +941,7 @@ __global__ void __launch_bounds__(256) k_greedy_small(const H* __restrict__ A, c
 }
 
 // diagnostic switches belong to the calling thread, like the 2-opt knobs (tsp2opt.hip: thread_local Opts)
-thread_local int g_greedy_small_k1 = 1; // tsp2opt_debug_greedy_cycles enable = 2 / 3: small maps on chip or not
+thread_local int t_greedy_onchip = 1; // tsp2opt_debug_greedy_cycles enable = 2 / 3: small maps on chip or not
 constexpr int kGreedyMaxN = 10200;      // partner indices are 16-bit, 12 B of LDS state per node
 
 // entries the prepare kernel extracts per node and the merge loop walks before it rescans a row: the row's
@@ -968,19 +966,19 @@ inline GreedyWs greedy_ws(int64_t num_maps, int n)
     return w;
 }
 
-thread_local int g_greedy_prof_on = 0;
+thread_local int t_greedy_prof_on = 0;
 
 template <typename H>
 int greedy_t(const void* heat, const double* points, int64_t* tours, int64_t num_maps, int n, int mpi,
              void* ws, hipStream_t stream)
 {
     const H* A = static_cast<const H*>(heat);
-    if (n <= kGreedySmallN && g_greedy_small_k1) {       // everything on chip: no key matrix, no workspace
+    if (n <= kGreedySmallN && t_greedy_onchip) {       // everything on chip: no key matrix, no workspace
         const size_t lds = greedy_small_lds(n);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_small<H>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_greedy_small<H>, dim3((unsigned)num_maps), dim3(n <= 64 ? 128 : 256), lds, stream, A, points,
-                           tours, num_maps, n, mpi, g_greedy_prof_on);
+                           tours, num_maps, n, mpi, t_greedy_prof_on);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -1001,7 +999,7 @@ int greedy_t(const void* heat, const double* points, int64_t* tours, int64_t num
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)num_maps), dim3(n <= 128 ? 64 : n <= 2048 ? 256 : 1024), lds, stream, Kd,
-                       A, points, lkey, lj, nb, tours, num_maps, n, mpi, greedy_rounds(n), g_greedy_prof_on);
+                       A, points, lkey, lj, nb, tours, num_maps, n, mpi, greedy_rounds(n), t_greedy_prof_on);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1050,14 +1048,14 @@ extern "C" int tsp2opt_debug_greedy_cycles(int32_t enable, int32_t device, uint6
     DeviceGuard guard(device);
     if (!guard.ok) return fail(TSP2OPT_E_HIP, "hipSetDevice failed");
     HIP_TRY(hipDeviceSynchronize());
-    if (enable == 2 || enable == 3) { g_greedy_small_k1 = enable == 2; return 0; }
+    if (enable == 2 || enable == 3) { t_greedy_onchip = enable == 2; return 0; }
     if (enable) {
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_greedy_prof), z, sizeof(z)));
-        g_greedy_prof_on = 1;
+        t_greedy_prof_on = 1;
         return 0;
     }
-    g_greedy_prof_on = 0;
+    t_greedy_prof_on = 0;
     if (out8) HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_greedy_prof), 8 * sizeof(unsigned long long)));
     return 0;
 }

@@ -1,46 +1,90 @@
-"""Diagnostic fuzz of the greedy decoder: a grid of N, dense / sparse (kNN-masked) / tie-heavy heat maps,
-against the CPU oracle (bit-exact tours).   python tools/fuzz_greedy.py [lo] [hi] [step]
+#!/usr/bin/env python3
+"""tools/fuzz_greedy.py -- randomized differential test of the greedy decoders against the CPU oracle.
+
+    python tools/fuzz_greedy.py [--seconds 120] [--seed 1] [--max-n 700]
+
+Every case draws a size, a dtype, a point layout (uniform / grid / clustered / with coincident points) and a
+heat-map kind (dense random, distance-proportional with tiny noise = near-ties everywhere, thresholded with
+exact zeros, kNN lists with duplicates), decodes it with the dense HIP decoder -- and, for list inputs, with
+the sparse one -- and requires the oracle's tours.  Prints one JSON line; exit status 1 on any mismatch.
 """
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import argparse, json, os, sys, time
 import numpy as np, torch
-from ml4tspbench_amd import greedy_decode_device
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ml4tspbench_amd as amd
 from oracle import greedy_oracle
 
-lo = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-hi = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-step = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120)
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--max-n", type=int, default=700)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
 dev = torch.device("cuda", 0)
-bad = []
-for n in range(lo, hi + 1, step):
-    rng = np.random.default_rng(n)
-    for kind in ("dense", "sparse", "ties", "grid"):
-        for dtype in (np.float32, np.float64):
-            inst, mpi = 2, 2
-            pts = rng.random((inst, n, 2))
-            heat = rng.random((inst * mpi, n, n))
-            if kind == "sparse":                       # only a few nonzero entries per row, rest exactly 0
-                k = min(n - 1, 5)
-                thr = np.sort(heat, axis=2)[:, :, n - k][:, :, None]
-                heat = np.where(heat >= thr, heat, 0.0)
-            elif kind == "ties":                       # quantised values: many equal keys at equal distances do not
-                heat = np.round(heat * 4) / 4          # exist here, but equal heat values stress the list refills
-            elif kind == "grid":                       # lattice points + quantised heat: exact key ties
-                side = int(np.ceil(np.sqrt(n)))
-                g = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2)[:n] / side
-                pts = np.stack([g, g[::-1]]).astype(np.float64)
-                heat = np.round(heat * 2) / 2
-            heat = heat.astype(dtype)
-            got = greedy_decode_device(torch.from_numpy(heat).to(dev), torch.from_numpy(pts).to(dev),
-                                       maps_per_instance=mpi)
-            torch.cuda.synchronize()
-            got = got.cpu().numpy()
-            for m in range(inst * mpi):
-                ref = greedy_oracle.greedy(pts[m // mpi], heat[m])
-                if not np.array_equal(got[m], ref[0]):
-                    bad.append((n, kind, dtype.__name__, m))
-                    print("MISMATCH", n, kind, dtype.__name__, m, flush=True)
-                    break
-    if n % 25 == 0:
-        print("..", n, flush=True)
-print("done", lo, hi, step, "bad:", bad[:20], len(bad))
+t_end = time.time() + a.seconds
+cases = fails = 0
+kinds = {}
+last = time.time()
+while time.time() < t_end:
+    n = int(rng.choice([rng.integers(2, 20), rng.integers(20, 130), rng.integers(130, 520), rng.integers(520, a.max_n + 1)]))
+    inst, mpi = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    dtype = np.float32 if rng.random() < 0.6 else np.float64
+    layout = rng.choice(["uniform", "grid", "clustered", "coincident"])
+    if layout == "grid":
+        g = int(np.ceil(np.sqrt(n)))
+        base = np.stack(np.meshgrid(np.arange(g), np.arange(g)), -1).reshape(-1, 2)[:n] / g
+        pts = np.stack([base[rng.permutation(n)] for _ in range(inst)])
+    elif layout == "clustered":
+        pts = 0.5 + 0.01 * rng.standard_normal((inst, n, 2))
+    else:
+        pts = rng.random((inst, n, 2))
+        if layout == "coincident" and n > 4:
+            pts[:, 1] = pts[:, 3]
+    d = np.sqrt(((pts[:, :, None] - pts[:, None]) ** 2).sum(-1))
+    kind = rng.choice(["dense", "near_ties", "thresholded", "knn"])
+    key = f"{kind}/{layout}"
+    kinds[key] = kinds.get(key, 0) + 1
+    B = inst * mpi
+    ok = True
+    if kind == "knn" and n >= 4:
+        k = int(rng.integers(2, min(n, 24)))
+        eis, vals = [], []
+        for q in range(inst):
+            nn = np.argsort(d[q], axis=1)[:, :k]
+            e0, e1 = np.repeat(np.arange(n), k), nn.reshape(-1)
+            dup = rng.integers(0, len(e0), size=int(rng.integers(0, 6)))
+            pad = rng.integers(0, n, size=(2, 6 - len(dup)))               # equal list lengths per instance
+            e0 = np.concatenate([e0, e0[dup], pad[0]]); e1 = np.concatenate([e1, e1[dup], pad[1]])
+            eis.append(np.stack([e0, e1]).astype(np.int64))
+        ei = np.stack(eis)
+        vals = (rng.random((B, ei.shape[2])) + 0.01).astype(dtype)
+        if rng.random() < 0.3:
+            vals[:, rng.integers(0, vals.shape[1], size=5)] = 0
+        dense = np.stack([greedy_oracle.densify(vals[m:m + 1], ei[m // mpi], n)[0] for m in range(B)])
+        ref = np.concatenate([greedy_oracle.greedy(pts[m // mpi], dense[m:m + 1]) for m in range(B)])
+        got_s = amd.greedy_decode_sparse_device(torch.from_numpy(vals).to(dev), torch.from_numpy(ei).to(dev),
+                                                torch.from_numpy(pts).to(dev), maps_per_instance=mpi).cpu().numpy()
+        ok &= bool(np.array_equal(got_s, ref))
+        heat = dense
+    else:
+        if kind == "near_ties":
+            eps = 10.0 ** rng.uniform(-15, -4.5)
+            heat = (0.4 * np.repeat(d, mpi, axis=0) * (1 + eps * rng.standard_normal((B, n, n)))).astype(dtype)
+        else:
+            heat = rng.random((B, n, n)).astype(dtype)
+            if kind == "thresholded":
+                heat[heat < rng.uniform(0.3, 0.95)] = 0
+        ref = np.concatenate([greedy_oracle.greedy(pts[m // mpi], heat[m:m + 1]) for m in range(B)])
+    got = amd.greedy_decode_device(torch.from_numpy(np.ascontiguousarray(heat)).to(dev), torch.from_numpy(pts).to(dev),
+                                   maps_per_instance=mpi).cpu().numpy()
+    ok &= bool(np.array_equal(got, ref))
+    cases += 1
+    if not ok:
+        fails += 1
+        print(json.dumps({"mismatch": {"n": n, "inst": inst, "mpi": mpi, "dtype": str(np.dtype(dtype)), "layout": str(layout),
+                                       "kind": str(kind), "case": cases, "seed": a.seed}}), flush=True)
+    if time.time() - last > 30:
+        print(f"... {cases} cases, {fails} mismatches", file=sys.stderr, flush=True)
+        last = time.time()
+print(json.dumps({"cases": cases, "mismatches": fails, "seed": a.seed, "by_kind": kinds}))
+sys.exit(1 if fails else 0)
