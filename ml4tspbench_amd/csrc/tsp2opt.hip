@@ -426,6 +426,8 @@ CPlan make_cluster_plan(const Opts& o, int n, int dtype, int cs_cap, bool smalle
                 if (NSw < 1) NSw = 1;
                 if (NSw > rmw) NSw = rmw;
                 const int MS = (rmw + NSw - 1) / NSw;
+                NSw = (rmw + MS - 1) / MS;              // no more row segments than MS steps each need: the walked
+                                                        // rows overshoot the band by less than one segment
                 if (MS < 4 && cs > 2) continue;         // too little work per cluster barrier
                 const int units = GPw * NSw;
                 const int passes = (units + nt - 1) / nt;
@@ -435,7 +437,9 @@ CPlan make_cluster_plan(const Opts& o, int n, int dtype, int cs_cap, bool smalle
                 // (positions [0, n + 12), indices wrapping at n / 4 groups) when 4 divides n, else the window
                 // is extended to the last walked column; cr > 1: column window of the tile + row band arrays
                 const bool shared = cr == 1;
-                const bool wrap = shared && n % 4 == 0;
+                // (the wrap is a single conditional subtraction: the last walked column block, row overshoot and
+                //  both streams included, must stay below twice the wrap point, else the extended window is used)
+                const bool wrap = shared && n % 4 == 0 && NSw * MS + 2 * GP + 8 <= 2 * (n / 4);
                 int Qw;
                 if (wrap) Qw = n / 4 + 4;
                 else if (shared) Qw = NSw * MS + 2 * GP + 4;
