@@ -36,6 +36,8 @@ try:
         layout = rng.choice(["uniform", "grid", "clustered", "duplicates", "offset"])
         inst = int(rng.integers(1, 4))
         tpi = int(rng.integers(1, 5))
+        if n > 1500:                    # oracle time
+            inst, tpi = min(inst, 2), min(tpi, 2)
         if layout == "grid":
             pts = rng.integers(0, max(2, int(np.sqrt(n))), size=(inst, n, 2)).astype(np.float64)
         elif layout == "clustered":
@@ -58,6 +60,8 @@ try:
         # the oracle costs iterations x N^2 / 2 per tour: keep a case near a second of CPU
         if n > 400:
             cap = min(cap, 300)
+        if n > 1500:
+            cap = min(cap, 60)
         variant = rng.choice(["auto", "one_wg", "cluster2", "cluster4", "lockstep"])
         mode = {"auto": -1, "one_wg": 0, "cluster2": 2, "cluster4": 4, "lockstep": -1}[str(variant)]
         L.tsp2opt_debug_cluster_mode(mode)
