@@ -182,7 +182,7 @@ int64_t tsp2opt_greedy_workspace_bytes(int64_t num_maps, int32_t n, int32_t heat
  * all have the key -0.0 and are taken, after every listed edge, in flat-index order -- the tie rule of the
  * dense entry point and of the oracle (the reference's order among equal keys is numpy's unstable argsort).
  * A listed pair whose heat sum is negative (its key would sort after the unlisted pairs) or a node with more
- * than 8192 listed edges gives TSP2OPT_E_UNSUPPORTED: densify and call tsp2opt_greedy_decode.  n <= 10900.
+ * than 7000 listed edges gives TSP2OPT_E_UNSUPPORTED: densify and call tsp2opt_greedy_decode.  n <= 10900.
  * The call synchronises `hip_stream` (it reads back an error word).  Diagnostics of heat map 0 are left in
  * the workspace at byte 64 as eight uint64: 10 ns ticks of set-up / listed-edge loop / unlisted pairs /
  * closing walk, then rounds, rounds that fell back to one exactly compared edge, 0, merges made from listed

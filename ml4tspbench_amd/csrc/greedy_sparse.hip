@@ -40,7 +40,7 @@
 namespace t2o {
 
 constexpr int kSpMaxN = 10900;          // 15 B of LDS state per node
-constexpr int kSpMaxRow = 8192;         // entries of one row the rank sorts accept
+constexpr int kSpMaxRow = 7000;         // entries of one row the row kernels accept (22 B of LDS each)
 
 // ---- structure phase ---------------------------------------------------------------------------------
 // blockIdx.y = instance in the structure kernels: its edge list ei + inst*2E, its rows at inst*(n+1), its
@@ -152,12 +152,16 @@ __global__ void __launch_bounds__(256) k_sp_fill(const int64_t* __restrict__ ei,
 }
 
 // one wave per row: entries ordered by (partner, edge id, direction); ucnt[i] = distinct partners, and the
-// first entry of every partner carries bit 31 of its srt_e word (edge ids stay below 2^30)
+// first entry of every partner carries bit 31 of its srt_e word (edge ids stay below 2^30).  The row is staged
+// in LDS as 64-bit keys (partner << 32 | edge id and direction); an entry's rank is the number of smaller keys,
+// and it is a partner's first entry iff none of them has the same partner.
 constexpr int kHeadBit = (int)0x80000000u;
 __global__ void __launch_bounds__(64) k_sp_rowsort(const int* __restrict__ off, const uint16_t* __restrict__ ent_j,
                                                    const int* __restrict__ ent_e, uint16_t* __restrict__ srt_j,
                                                    int* __restrict__ srt_e, int* __restrict__ ucnt, int n, int64_t E)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* ks = reinterpret_cast<unsigned long long*>(smem);
     const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= n) return;
     off += (size_t)blockIdx.y * ((size_t)n + 1);
@@ -167,110 +171,123 @@ __global__ void __launch_bounds__(64) k_sp_rowsort(const int* __restrict__ off, 
     srt_j += (size_t)blockIdx.y * 2 * (size_t)E;
     srt_e += (size_t)blockIdx.y * 2 * (size_t)E;
     const int o = off[i], L = off[i + 1] - o;
-    for (int x = lane; x < L; x += 64) {
-        const unsigned long long kx = ((unsigned long long)ent_j[o + x] << 32) | (unsigned)ent_e[o + x];
-        int rank = 0;
-        for (int y = 0; y < L; ++y) {
-            const unsigned long long ky = ((unsigned long long)ent_j[o + y] << 32) | (unsigned)ent_e[o + y];
-            rank += ky < kx ? 1 : 0;
-        }
-        srt_j[o + rank] = (uint16_t)(kx >> 32);
-        srt_e[o + rank] = (int)(unsigned)kx;
-    }
+    for (int x = lane; x < L; x += 64) ks[x] = ((unsigned long long)ent_j[o + x] << 32) | (unsigned)ent_e[o + x];
     __syncthreads();
     int heads = 0;
     for (int x0 = 0; x0 < L; x0 += 64) {
         const int x = x0 + lane;
-        const bool head = x < L && (x == 0 || srt_j[o + x] != srt_j[o + x - 1]);
-        if (head) srt_e[o + x] |= kHeadBit;
+        bool head = false;
+        if (x < L) {
+            const unsigned long long kx = ks[x];
+            const unsigned jx = (unsigned)(kx >> 32);
+            int rank = 0, same = 0;
+            for (int y = 0; y < L; ++y) {               // every lane reads the same word: an LDS broadcast
+                const unsigned long long ky = ks[y];
+                const int lt = ky < kx ? 1 : 0;
+                rank += lt;
+                same += (lt && (unsigned)(ky >> 32) == jx) ? 1 : 0;
+            }
+            head = same == 0;
+            srt_j[o + rank] = (uint16_t)jx;
+            srt_e[o + rank] = (int)(unsigned)kx | (head ? kHeadBit : 0);
+        }
         heads += __popcll(__ballot(head));
     }
     if (lane == 0) ucnt[i] = heads;
 }
 
 // ---- per heat map: sums per partner, keys, candidate lists ---------------------------------------------
-// one wave per (row, heat map), a lane per distinct partner.  list_j / list_k / list_S [map][uoff[i] + rank]:
-// partners with S > 0 by exact (key, j)
+// one wave per (row, instance), a lane per distinct partner; what the heat maps of an instance share -- where
+// each partner's entries start, the partner, its distance -- is prepared once, then every heat map of the
+// instance sums its values, keys them and rank-sorts the partners with S > 0 by exact (key, j) into
+// list_j / list_k [map][uoff[i] + rank].
 template <typename H>
 __global__ void __launch_bounds__(64) k_sp_rowkeys(const H* __restrict__ vals, const double* __restrict__ points,
                                                    const int* __restrict__ off, const uint16_t* __restrict__ srt_j,
                                                    const int* __restrict__ srt_e, const int* __restrict__ uoff,
                                                    uint16_t* __restrict__ list_j, float* __restrict__ list_k,
-                                                   int* __restrict__ len, int n, int64_t E, int mpi, int cap,
-                                                   int* __restrict__ err)
+                                                   int* __restrict__ len, int64_t num_maps, int n, int64_t E, int mpi,
+                                                   int cap, int* __restrict__ err)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int i = blockIdx.x, lane = threadIdx.x;
-    const int64_t m = blockIdx.y;
-    const size_t inst = (size_t)(m / mpi), E2 = 2 * (size_t)E;
+    const size_t inst = blockIdx.y, E2 = 2 * (size_t)E;
     off += inst * ((size_t)n + 1);
     uoff += inst * ((size_t)n + 1);
     srt_j += inst * E2;
     srt_e += inst * E2;
     const int o = off[i], L = off[i + 1] - o;
     const int ub = uoff[i];
-    double* ck = reinterpret_cast<double*>(smem);                       // kept partners, compact: key, node
-    uint16_t* cj = reinterpret_cast<uint16_t*>(smem + sizeof(double) * (size_t)cap);
-    uint16_t* hd = cj + cap;                                            // first entry of the h-th partner
+    double* ck = reinterpret_cast<double*>(smem);                       // kept partners of one map, compact: key,
+    double* pd = ck + cap;                                              // ... every partner's distance,
+    uint16_t* cj = reinterpret_cast<uint16_t*>(pd + cap);               // kept partner's node,
+    uint16_t* hd = cj + cap;                                            // first entry of the h-th partner,
+    uint16_t* pj = hd + cap;                                            // its node
+    const double* P = points + inst * (size_t)n * 2;
+    const double xi = P[2 * i], yi = P[2 * i + 1];
     int U = 0;
     for (int x0 = 0; x0 < L; x0 += 64) {
         const int x = x0 + lane;
         const bool head = x < L && srt_e[o + x] < 0;
         const unsigned long long bal = __ballot(head);
-        if (head) hd[U + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)x;
+        if (head) {
+            const int h = U + __popcll(bal & ((1ull << lane) - 1ull));
+            const int j = srt_j[o + x];
+            const double dx = xi - P[2 * j], dy = yi - P[2 * j + 1];
+            hd[h] = (uint16_t)x;
+            pj[h] = (uint16_t)j;
+            pd[h] = sqrt(dx * dx + dy * dy);
+        }
         U += __popcll(bal);
     }
     __syncthreads();
-    const H* v = vals + (size_t)m * (size_t)E;
-    const double* P = points + inst * (size_t)n * 2;
-    const double xi = P[2 * i], yi = P[2 * i + 1];
-    int K = 0;
-    for (int h0 = 0; h0 < U; h0 += 64) {
-        const int h = h0 + lane;
-        double key = INFINITY;
-        H S = (H)0;
-        int j = 0;
-        if (h < U) {
-            const int xs = hd[h], xe = h + 1 < U ? (int)hd[h + 1] : L;
-            j = srt_j[o + xs];
-            H fwd = (H)0, bwd = (H)0;
-            for (int y = xs; y < xe; ++y) {                             // the entries of one pair, by edge id
-                const int e2 = srt_e[o + y] & ~kHeadBit;
-                const H w = v[e2 >> 1];
-                if (e2 & 1) bwd += w; else fwd += w;
+    for (int64_t m = (int64_t)inst * mpi; m < (int64_t)(inst + 1) * mpi && m < num_maps; ++m) {
+        const H* v = vals + (size_t)m * (size_t)E;
+        int K = 0;
+        for (int h0 = 0; h0 < U; h0 += 64) {
+            const int h = h0 + lane;
+            double key = INFINITY;
+            if (h < U) {
+                const int xs = hd[h], xe = h + 1 < U ? (int)hd[h + 1] : L;
+                H fwd = (H)0, bwd = (H)0;
+                for (int y = xs; y < xe; ++y) {                         // the entries of one pair, by edge id
+                    const int e2 = srt_e[o + y] & ~kHeadBit;
+                    const H w = v[e2 >> 1];
+                    if (e2 & 1) bwd += w; else fwd += w;
+                }
+                const H S = fwd + bwd;                                  // coo(i,j).toarray() + coo(j,i).toarray()
+                if (S < (H)0 || S != S) atomicOr(err, 4);
+                if (S > (H)0) {
+                    key = -(double)S / pd[h];
+                    if (key != key) key = INFINITY;
+                }
             }
-            S = fwd + bwd;                                              // coo(i,j).toarray() + coo(j,i).toarray()
-            if (S < (H)0 || S != S) atomicOr(err, 4);
-            if (S > (H)0) {
-                const double dx = xi - P[2 * j], dy = yi - P[2 * j + 1];
-                key = -(double)S / sqrt(dx * dx + dy * dy);
-                if (key != key) key = INFINITY;
+            const bool keep = key != INFINITY;
+            const unsigned long long bal = __ballot(keep);
+            if (keep) {
+                const int c = K + __popcll(bal & ((1ull << lane) - 1ull));
+                ck[c] = key;
+                cj[c] = pj[h];
             }
+            K += __popcll(bal);
         }
-        const bool keep = key != INFINITY;
-        const unsigned long long bal = __ballot(keep);
-        if (keep) {
-            const int c = K + __popcll(bal & ((1ull << lane) - 1ull));
-            ck[c] = key;
-            cj[c] = (uint16_t)j;
+        __syncthreads();
+        uint16_t* outJ = list_j + (size_t)m * E2 + ub;
+        float* outK = list_k + (size_t)m * E2 + ub;
+        for (int c = lane; c < K; c += 64) {
+            const double kc = ck[c];
+            const unsigned jc = cj[c];
+            int rank = 0;
+            for (int y = 0; y < K; ++y) {
+                const double ky = ck[y];
+                rank += (ky < kc || (ky == kc && (unsigned)cj[y] < jc)) ? 1 : 0;
+            }
+            outJ[rank] = (uint16_t)jc;
+            outK[rank] = (float)kc;                                     // what the merge loop compares first
         }
-        K += __popcll(bal);
+        if (lane == 0) len[(size_t)m * n + i] = K;
+        __syncthreads();                                                // ck / cj are reused by the next heat map
     }
-    __syncthreads();
-    uint16_t* outJ = list_j + (size_t)m * E2 + ub;
-    float* outK = list_k + (size_t)m * E2 + ub;
-    for (int c = lane; c < K; c += 64) {
-        const double kc = ck[c];
-        const unsigned jc = cj[c];
-        int rank = 0;
-        for (int y = 0; y < K; ++y) {
-            const double ky = ck[y];
-            rank += (ky < kc || (ky == kc && (unsigned)cj[y] < jc)) ? 1 : 0;
-        }
-        outJ[rank] = (uint16_t)jc;
-        outK[rank] = (float)kc;                                         // what the merge loop compares first
-    }
-    if (lane == 0) len[(size_t)m * n + i] = K;
 }
 
 // ---- merge loop ------------------------------------------------------------------------------------------
@@ -658,25 +675,26 @@ int greedy_sparse_t(const void* values, const int64_t* ei, const double* points,
     const unsigned ig = (unsigned)inst;
     hipLaunchKernelGGL(k_sp_count, dim3(eg, ig), dim3(256), 0, stream, ei, E, n, cnt, err);
     hipLaunchKernelGGL(k_sp_scan, dim3(ig), dim3(1024), 0, stream, cnt, off, cur, n, kSpMaxRow, err);
-    hipLaunchKernelGGL(k_sp_fill, dim3(eg, ig), dim3(256), 0, stream, ei, E, n, off, cur, entj, ente);
-    hipLaunchKernelGGL(k_sp_rowsort, dim3((unsigned)n, ig), dim3(64), 0, stream, off, entj, ente, srtj, srte, ucnt, n, E);
-    hipLaunchKernelGGL(k_sp_scan, dim3(ig), dim3(1024), 0, stream, ucnt, uoff, (int*)nullptr, n, 0, err);
-    HIP_TRY(hipGetLastError());
-    // a row's keys and sums are staged in LDS: rows are capped at kSpMaxRow entries (checked on the device)
-    const size_t rlds = (size_t)kSpMaxRow * (sizeof(double) + 4);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_rowkeys<H>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+    // the error word and the longest row (it sizes the LDS of the two row kernels) are known after the scan
     int eh[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(eh, err, 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     int errh = eh[0];
     if (errh & 1) return fail(TSP2OPT_E_ARG, "edge_index has an entry outside [0, n)");
-    if (errh & 2) return fail(TSP2OPT_E_UNSUPPORTED, "a node has more than 8192 listed edges: use the dense decoder");
-    // the longest row bounds the LDS request of the key kernel (one wave per row: short rows, many per CU)
+    if (errh & 2) return fail(TSP2OPT_E_UNSUPPORTED, "a node has more than 7000 listed edges: use the dense decoder");
     const int cap = std::max(eh[1], 1);
-    const size_t klds = ((size_t)cap * (sizeof(double) + 4) + 15) & ~(size_t)15;
-    hipLaunchKernelGGL(k_sp_rowkeys<H>, dim3((unsigned)n, (unsigned)num_maps), dim3(64), klds, stream,
-                       static_cast<const H*>(values), points, off, srtj, srte, uoff, lj, lk, len, n, E, mpi, cap, err);
+    const size_t slds = ((size_t)cap * 8 + 15) & ~(size_t)15;
+    const size_t klds = ((size_t)cap * 22 + 15) & ~(size_t)15;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_rowsort),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_rowkeys<H>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)klds));
+    hipLaunchKernelGGL(k_sp_fill, dim3(eg, ig), dim3(256), 0, stream, ei, E, n, off, cur, entj, ente);
+    hipLaunchKernelGGL(k_sp_rowsort, dim3((unsigned)n, ig), dim3(64), slds, stream, off, entj, ente, srtj, srte, ucnt, n, E);
+    hipLaunchKernelGGL(k_sp_scan, dim3(ig), dim3(1024), 0, stream, ucnt, uoff, (int*)nullptr, n, 0, err);
+    hipLaunchKernelGGL(k_sp_rowkeys<H>, dim3((unsigned)n, ig), dim3(64), klds, stream,
+                       static_cast<const H*>(values), points, off, srtj, srte, uoff, lj, lk, len, num_maps, n, E, mpi,
+                       cap, err);
     HIP_TRY(hipGetLastError());
     const size_t lds = (size_t)n * 15 + 64;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_sparse<H>),

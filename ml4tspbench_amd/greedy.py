@@ -54,7 +54,7 @@ def greedy_decode_sparse_device(values: torch.Tensor, edge_index: torch.Tensor, 
     (one list per instance, shared by its maps_per_instance heat maps; (2, E) for a single instance),
     points (I, N, 2), all on one HIP device, B == I * maps_per_instance.
     Returns tours (B, N+1) int64 on the device.  Raises ``Tsp2optError`` (code -2) for inputs the sparse
-    kernels do not take (negative heat sums, a node with more than 8192 listed edges): densify then.
+    kernels do not take (negative heat sums, a node with more than 7000 listed edges): densify then.
     The batch is decoded in as few library calls as keep each call's workspace (24 B per listed edge at one
     heat map per instance) under ``workspace_limit_bytes``; a single instance is never split."""
     if values.device.type != "cuda" or points.device != values.device:
