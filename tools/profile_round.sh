@@ -1,11 +1,11 @@
 #!/bin/bash
 # tools/profile_round.sh TAG [stage ...] -- evidence for profiles/: bench lines, rocprofv3 kernel
 # stats, PMC passes, phase breakdowns.  Stages: bench kt pmc configs ktconfigs variants phases dist strong
-# pipeline lsops (default all).
+# pipeline lsops pmcconfigs (default all).
 # Everything lands in gpurun_out/TAG_*.  Run on the GPU box from the repo root.
 set -u
 TAG=${1:-rXX}; shift || true
-STAGES=${*:-bench kt pmc configs ktconfigs variants phases dist strong pipeline lsops}
+STAGES=${*:-bench kt pmc configs ktconfigs pmcconfigs variants phases dist strong pipeline lsops}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out
 for st in $STAGES; do
@@ -24,6 +24,13 @@ for st in $STAGES; do
       echo "   kernel trace $c"
       timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${TAG}_kt_$c -- python bench.py --config $c --steps 2 --warmup 1 --no-cpu > $O/${TAG}_kt_$c.log 2>&1 || exit 1
       cp $(find /tmp/${TAG}_kt_$c -name '*kernel_stats.csv' | head -1) $O/${TAG}_kernel_stats_$c.csv
+    done ;;
+  pmcconfigs) # one SQ pass per other configuration (needs the configs stage's bench lines for the iteration counts)
+    for ct in tsp50:1280 tsp100:10000 tsp1000:128 tsp10000:16; do
+      c=${ct%%:*}; t=${ct##*:}
+      echo "   pmc $c"
+      timeout -s KILL 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d /tmp/${TAG}_pv_$c -- python bench.py --config $c --steps 1 --warmup 0 --no-cpu > $O/${TAG}_pv_$c.log 2>&1 || exit 1
+      python tools/summarize_pmc_valu.py $c $(find /tmp/${TAG}_pv_$c -name '*counter_collection.csv' | head -1) $O/${TAG}_bench_$c.json $t > $O/${TAG}_${c}_pmc_valu.json || exit 1
     done ;;
   pipeline) for c in tsp50 tsp100 tsp500; do
       echo "   pipeline $c (dense heat maps)"
