@@ -1,10 +1,10 @@
 """Diagnostic fuzz: every N in a range through the GPU path against the CPU oracle (bit-exact).
-    python tools/fuzz_every_n.py [lo] [hi] [step] [cluster workgroups, 0 = automatic kernel choice] [variant]
+    python tests/fuzz/fuzz_every_n.py [lo] [hi] [step] [cluster workgroups, 0 = automatic kernel choice] [variant]
 Prints the N that differ (nothing = all equal).  The same loop is in tests/test_gpu_parity.py at a coarser grid.
 """
 import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import ml4tspbench_amd as amd
 from ml4tspbench_amd import _lib

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""tools/fuzz_greedy.py -- randomized differential test of the greedy decoders against the CPU oracle.
+"""tests/fuzz/fuzz_greedy.py -- randomized differential test of the greedy decoders against the CPU oracle.
 
-    python tools/fuzz_greedy.py [--seconds 120] [--seed 1] [--max-n 700]
+    python tests/fuzz/fuzz_greedy.py [--seconds 120] [--seed 1] [--max-n 700]
 
 Every case draws a size, a dtype, a point layout (uniform / grid / clustered / with coincident points) and a
 heat-map kind (dense random, distance-proportional with tiny noise = near-ties everywhere, thresholded with
@@ -10,7 +10,7 @@ the sparse one -- and requires the oracle's tours.  Prints one JSON line; exit s
 """
 import argparse, json, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ml4tspbench_amd as amd
 from oracle import greedy_oracle
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""tools/fuzz_ls_ops.py -- randomized differential test of the other move operators against the C oracle.
+"""tests/fuzz/fuzz_ls_ops.py -- randomized differential test of the other move operators against the C oracle.
 
-    python tools/fuzz_ls_ops.py [--seconds 120] [--seed 1] [--max-n 260]
+    python tests/fuzz/fuzz_ls_ops.py [--seconds 120] [--seed 1] [--max-n 260]
 
 Cases: one operator call (two-opt variant / relocate; all moves or a fixed row per tour; plain or guided
 weights with random penalty matrices), or the local_search loop; uniform / integer-grid (many equal deltas) /
@@ -9,7 +9,7 @@ clustered points.  Tours and deltas (rounds) must be identical.  One JSON line; 
 """
 import argparse, json, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ml4tspbench_amd as amd
 from oracle import ls_oracle
 

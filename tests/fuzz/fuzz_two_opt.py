@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""tools/fuzz_two_opt.py -- randomized differential test of tsp2opt_solve against the CPU oracle.
+"""tests/fuzz/fuzz_two_opt.py -- randomized differential test of tsp2opt_solve against the CPU oracle.
 
-    python tools/fuzz_two_opt.py [--seconds 180] [--seed 1] [--max-n 900]
+    python tests/fuzz/fuzz_two_opt.py [--seconds 180] [--seed 1] [--max-n 900]
 
 Every case draws a size, a dtype, a point layout (uniform / integer grid / clustered / duplicates / offset),
 start tours (random, or identity = many equal deltas on a grid), a termination mode (independent, or groups
@@ -11,7 +11,7 @@ iteration counts and sweep counts bit for bit.  One JSON line; exit status 1 on 
 """
 import argparse, json, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ml4tspbench_amd as amd
 from ml4tspbench_amd import _lib
 from oracle import two_opt_oracle

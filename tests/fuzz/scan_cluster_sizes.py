@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""tools/scan_cluster_sizes.py -- every n in a range through the forced cluster kernels (2, 4, 8 workgroups
+"""tests/fuzz/scan_cluster_sizes.py -- every n in a range through the forced cluster kernels (2, 4, 8 workgroups
 per tour) against the CPU oracle; prints the sizes (with their planned geometry) whose tours or iteration
 counts differ.  Found nothing after the planner fix of round 2 (n = 40 .. 700)."""
 import sys, os, ctypes, numpy as np, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ml4tspbench_amd as amd
 from ml4tspbench_amd import _lib
 from oracle import two_opt_oracle

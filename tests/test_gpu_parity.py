@@ -156,7 +156,7 @@ CLUSTER_CASES = [
     (1000, 9, np.float64, 5000, 2, 2), (1500, 1, np.float64, 300, 32, 2), (2000, 2, np.float64, 150, 5, 2),
     (2500, 1, np.float32, 120, 0, 0),
     # band kernel, shared rows, few long row segments: the walked columns used to run past twice the wrap point
-    # (found by tools/fuzz_two_opt.py at n = 180 .. 192); now the extended window is planned there
+    # (found by tests/fuzz/fuzz_two_opt.py at n = 180 .. 192); now the extended window is planned there
     (180, 4, np.float64, 5000, 2, 1), (188, 3, np.float64, 5000, 4, 1), (192, 2, np.float32, 5000, 2, 1),
     (184, 2, np.float64, 5000, 8, 1), (352, 2, np.float64, 5000, 2, 1),
 ]
