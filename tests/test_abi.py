@@ -92,3 +92,35 @@ def test_filter_class_256_runs_512_threads():
             if pl["filter_class"] == 256:
                 assert pl["threads"] <= 512, (n, pl)
     assert {128, 256, 512} <= seen
+
+
+def test_decoder_argument_validation_without_gpu():
+    """Host-side checks of the decoder entry points: sizes, dtypes, limits and null pointers are rejected
+    before any HIP call; the workspace queries are pure host arithmetic."""
+    from ml4tspbench_amd import _lib
+    L = _lib.lib()
+    F32, F64 = _lib.DTYPE_F32, _lib.DTYPE_F64
+    # dense: a fp32 key matrix + lists + neighbour table per heat map
+    w = L.tsp2opt_greedy_workspace_bytes(4, 500, F32)
+    assert 4 * 500 * 500 * 4 <= w < 4 * 500 * 500 * 4 + 4 * 500 * 64 + 4096
+    assert L.tsp2opt_greedy_workspace_bytes(4, 1, F32) < 0 and L.tsp2opt_greedy_workspace_bytes(4, 50, 7) < 0
+    assert L.tsp2opt_greedy_decode(None, None, None, 1, 50, 1, F32, 0, None, 0, None) == -1
+    assert L.tsp2opt_greedy_decode(None, None, None, 1, 20000, 1, F32, 0, None, 0, None) == -2
+    assert L.tsp2opt_greedy_decode(None, None, None, 0, 50, 1, F32, 0, None, 0, None) == 0      # nothing to do
+    # sparse: 12 B per listed edge and instance + 12 B per listed edge and heat map (+ per-node arrays)
+    n, E = 10000, 500000
+    one = L.tsp2opt_greedy_sparse_workspace_bytes(1, n, E, 1, F32)
+    assert 24 * E <= one < 24 * E + 64 * n + 8192
+    sixteen_maps = L.tsp2opt_greedy_sparse_workspace_bytes(16, n, E, 16, F32)     # one instance, 16 heat maps
+    assert 12 * E + 16 * 12 * E <= sixteen_maps < 12 * E + 16 * 12 * E + 16 * 64 * n + 8192
+    assert L.tsp2opt_greedy_sparse_workspace_bytes(16, n, E, 1, F64) >= 16 * 24 * E              # 16 instances
+    assert L.tsp2opt_greedy_sparse_workspace_bytes(1, n, E, 0, F32) < 0
+    assert L.tsp2opt_greedy_sparse_workspace_bytes(1, 1, E, 1, F32) < 0
+    bad = L.tsp2opt_greedy_decode_sparse
+    assert bad(None, None, None, None, 1, 50, 10, 1, F32, 0, None, 0, None) == -1               # null pointers
+    assert bad(None, None, None, None, 1, 20000, 10, 1, F32, 0, None, 0, None) == -2            # n > 10900
+    assert bad(None, None, None, None, 70000, 50, 10, 1, F32, 0, None, 0, None) == -2           # > 65535 heat maps
+    assert bad(None, None, None, None, 1, 50, 10, 0, F32, 0, None, 0, None) == -1               # maps_per_instance < 1
+    assert bad(None, None, None, None, 1, 50, 10, 1, 9, 0, None, 0, None) == -1                 # dtype
+    assert bad(None, None, None, None, 0, 50, 10, 1, F32, 0, None, 0, None) == 0
+    assert b"" != L.tsp2opt_last_error()
