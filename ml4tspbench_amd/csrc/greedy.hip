@@ -138,12 +138,20 @@ template <typename H>
 __global__ void __launch_bounds__(512) k_greedy_prepare(const H* __restrict__ A, const double* __restrict__ points,
                                                         float* __restrict__ Kd, float* __restrict__ lkey,
                                                         uint16_t* __restrict__ lj, int n, int maps_per_instance,
-                                                        int64_t map0, int topk_rounds)
+                                                        int64_t map0, int64_t maps_here, int topk_rounds)
 {
     __shared__ H tile[64][33];                          // tile[c][r] = A[c0 + c][i0 + r]
-    const int64_t b = map0 + blockIdx.y;
+    // Workgroups are dealt to the 8 XCDs (each with its own L2) round-robin in launch order: block id % 8
+    // selects the XCD, so all row bands of a heat map are given ids of one residue and follow each other there.
+    // The map (1 MB at n = 500) is then read from HBM once and the transposed tiles of the later bands hit that
+    // XCD's L2 (with bands spread over the XCDs the misaligned 128-byte column segments were fetched 2.8 times).
+    const int bands = (n + 31) / 32;
+    const unsigned lin = blockIdx.x, kq = lin >> 3;
+    const int64_t ml = (int64_t)(kq / (unsigned)bands) * 8 + (lin & 7u);
+    if (ml >= maps_here) return;
+    const int64_t b = map0 + ml;
     const int x = threadIdx.x, y = threadIdx.y, t = y * 64 + x;
-    const int i0 = blockIdx.x * 32;
+    const int i0 = (int)(kq % (unsigned)bands) * 32;
     const H* Ab = A + (size_t)b * n * n;
     float* Kb = Kd + (size_t)b * n * n;
     const double* P = points + (size_t)(b / maps_per_instance) * n * 2;
@@ -987,10 +995,12 @@ int greedy_t(const void* heat, const double* points, int64_t* tours, int64_t num
     float* Kd = reinterpret_cast<float*>(w8);
     float* lkey = reinterpret_cast<float*>(w8 + wl.off_lkey);
     uint16_t* lj = reinterpret_cast<uint16_t*>(w8 + wl.off_lj);
-    // grid.y is limited to 65535: prepare in slabs of heat maps
+    // prepare in slabs of heat maps (block ids stay below 2^31)
     for (int64_t b0 = 0; b0 < num_maps; b0 += 32768) {
-        const dim3 grid((unsigned)((n + 31) / 32), (unsigned)std::min<int64_t>(32768, num_maps - b0), 1);
-        hipLaunchKernelGGL((k_greedy_prepare<H>), grid, dim3(64, 8), 0, stream, A, points, Kd, lkey, lj, n, mpi, b0, greedy_rounds(n));
+        const int64_t here = std::min<int64_t>(32768, num_maps - b0);
+        const dim3 grid((unsigned)(((here + 7) / 8) * 8 * ((n + 31) / 32)), 1, 1);
+        hipLaunchKernelGGL((k_greedy_prepare<H>), grid, dim3(64, 8), 0, stream, A, points, Kd, lkey, lj, n, mpi, b0, here,
+                           greedy_rounds(n));
         HIP_TRY(hipGetLastError());
     }
     uint16_t* nb = reinterpret_cast<uint16_t*>(w8 + wl.off_nb);
