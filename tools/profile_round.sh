@@ -1,11 +1,11 @@
 #!/bin/bash
 # tools/profile_round.sh TAG [stage ...] -- evidence for profiles/: bench lines, rocprofv3 kernel
 # stats, PMC passes, phase breakdowns.  Stages: bench kt pmc configs ktconfigs variants phases dist strong
-# pipeline lsops pmcconfigs (default all).
+# pipeline lsops pmcconfigs pmcdecoder (default all).
 # Everything lands in gpurun_out/TAG_*.  Run on the GPU box from the repo root.
 set -u
 TAG=${1:-rXX}; shift || true
-STAGES=${*:-bench kt pmc configs ktconfigs pmcconfigs variants phases dist strong pipeline lsops}
+STAGES=${*:-bench kt pmc configs ktconfigs pmcconfigs pmcdecoder variants phases dist strong pipeline lsops}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out
 for st in $STAGES; do
@@ -32,6 +32,13 @@ for st in $STAGES; do
       timeout -s KILL 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d /tmp/${TAG}_pv_$c -- python bench.py --config $c --steps 1 --warmup 0 --no-cpu > $O/${TAG}_pv_$c.log 2>&1 || exit 1
       python tools/summarize_pmc_valu.py $c $(find /tmp/${TAG}_pv_$c -name '*counter_collection.csv' | head -1) $O/${TAG}_bench_$c.json $t > $O/${TAG}_${c}_pmc_valu.json || exit 1
     done ;;
+  pmcdecoder) # counters of the dense decoder's kernels (TSP-500 x 2048 heat maps)
+    n=0
+    for pass in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" FETCH_SIZE WRITE_SIZE; do
+      n=$((n+1))
+      timeout -s KILL 150 rocprofv3 --pmc $pass --output-format csv -d /tmp/${TAG}_pd$n -- python tools/pipeline_bench.py --config tsp500 --check 0 --steps 1 > $O/${TAG}_pd$n.log 2>&1 || exit 1
+    done
+    python tools/summarize_pmc_decoder.py $(find /tmp/${TAG}_pd1 -name '*counter_collection.csv' | head -1) $(find /tmp/${TAG}_pd2 -name '*counter_collection.csv' | head -1) $(find /tmp/${TAG}_pd3 -name '*counter_collection.csv' | head -1) > $O/${TAG}_decoder_tsp500_pmc.json || exit 1 ;;
   pipeline) for c in tsp50 tsp100 tsp500; do
       echo "   pipeline $c (dense heat maps)"
       timeout -k 10 250 python tools/pipeline_bench.py --config $c --steps 5 > $O/${TAG}_pipeline_$c.json 2> $O/${TAG}_pipeline_$c.err || exit 1
