@@ -4,7 +4,9 @@ Reference interface (read-only): ``search/greedy_search.py:19-74`` ``tsp_greedy`
 ``DECODING_CLASS[('tsp', 'greedy')]``, ``search/__init__.py:36``) on top of the Cython
 ``merge_cython`` (``search/cython_merge/sources/cython_merge.pyx:19-120``).  Same name, arguments
 and return value (a list of ``parallel_sampling`` tours, each a list of N+1 ints starting and ending
-at node 0); the work runs in ``csrc/greedy.hip`` (one wave per heat map, no N^2 sort).
+at node 0); the work runs in ``csrc/greedy.hip`` (dense heat maps: merge rounds, no N^2 sort) and
+``csrc/greedy_sparse.hip`` (``sparse_graph=True``: the ``(values, edge_index)`` lists of
+``greedy_search.py:39-47`` are decoded as lists instead of being densified).
 """
 from __future__ import annotations
 
@@ -12,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .two_opt import _resolve_device, _workspace
+from .two_opt import _resolve_device
 
 
 def greedy_decode_device(heat: torch.Tensor, points: torch.Tensor, *, maps_per_instance: int = 1) -> torch.Tensor:

@@ -18,7 +18,7 @@ There is no CPU path.
 from __future__ import annotations
 
 import time
-from typing import Optional, Union
+from typing import Optional
 
 import numpy as np
 import torch
