@@ -22,7 +22,6 @@ from typing import Union
 import numpy as np
 import torch
 
-from . import _lib
 from .two_opt import evaluate_tours, raise_on_status, tsp_2opt, two_opt_device, _resolve_device
 
 
