@@ -61,7 +61,15 @@ SYMBOLS = (
 
 
 class Tsp2optError(RuntimeError):
-    pass
+    """A negative return code of the library; ``code`` is that value (TSP2OPT_E_*), None when the error was
+    raised on the Python side."""
+
+    def __init__(self, message: str, code=None):
+        super().__init__(message)
+        self.code = code
+
+
+E_ARG, E_UNSUPPORTED, E_WORKSPACE, E_HIP = -1, -2, -3, -4
 
 
 def lib() -> ctypes.CDLL:
@@ -135,7 +143,7 @@ def lib() -> ctypes.CDLL:
 def check(rc: int, what: str) -> None:
     if rc < 0:
         msg = lib().tsp2opt_last_error()
-        raise Tsp2optError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+        raise Tsp2optError(f"{what} failed ({rc}): {msg.decode() if msg else ''}", code=int(rc))
 
 
 def plan(n: int, dtype: int = DTYPE_F64, device: int = -1) -> dict:

@@ -130,7 +130,7 @@ def tsp_greedy(adj_mat, np_points, edge_index_np=None, sparse_graph=False, paral
             tours = greedy_decode_sparse_device(vals, ei, pts.to(dev)[None], maps_per_instance=parallel_sampling)
             return [t.tolist() for t in tours.cpu().numpy()]
         except _lib.Tsp2optError as exc:
-            if "(-2)" not in str(exc):
+            if exc.code != _lib.E_UNSUPPORTED:
                 raise
         heat = torch.zeros((parallel_sampling, n, n), dtype=vals.dtype, device=dev)
         heat.index_put_((torch.arange(parallel_sampling, device=dev)[:, None].expand(-1, ei.shape[1]),
