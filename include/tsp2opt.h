@@ -29,7 +29,7 @@ extern "C" {
 /* return codes */
 #define TSP2OPT_OK              0
 #define TSP2OPT_E_ARG         (-1)     /* bad argument (null pointer, n < 1, sizes inconsistent) */
-#define TSP2OPT_E_UNSUPPORTED (-2)     /* n above the supported maximum                          */
+#define TSP2OPT_E_UNSUPPORTED (-2)     /* n above the supported maximum, or an input this entry point does not take (see there) */
 #define TSP2OPT_E_WORKSPACE   (-3)     /* workspace_bytes too small                              */
 #define TSP2OPT_E_HIP         (-4)     /* a HIP runtime call failed (message has the HIP error)  */
 
