@@ -958,6 +958,15 @@ inline int greedy_rounds(int n) { return kTopK; }
 
 inline size_t greedy_lds(int n) { return (size_t)n * 12 + 64; }
 
+// threads of a merge workgroup (one per heat map): 256 keep many maps resident; few maps of more than a few
+// hundred nodes get 1024 (more waves for the queued row rescans and the per-node phases; the chip is not full anyway)
+inline unsigned merge_threads(int n, int64_t num_maps)
+{
+    if (n <= 128) return 64;
+    if (n > 2048 || (n > 512 && num_maps <= 512)) return 1024;
+    return 256;
+}
+
 struct GreedyWs {
     size_t off_lkey, off_lj, off_nb, total;     // key matrices at 0
 };
@@ -1008,7 +1017,7 @@ int greedy_t(const void* heat, const double* points, int64_t* tours, int64_t num
     auto kern = n <= 128 ? k_greedy<H, 2> : n <= 256 ? k_greedy<H, 4> : n <= 512 ? k_greedy<H, 8> : k_greedy<H, 0>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)num_maps), dim3(n <= 128 ? 64 : n <= 2048 ? 256 : 1024), lds, stream, Kd,
+    hipLaunchKernelGGL(kern, dim3((unsigned)num_maps), dim3(merge_threads(n, num_maps)), lds, stream, Kd,
                        A, points, lkey, lj, nb, tours, num_maps, n, mpi, greedy_rounds(n), t_greedy_prof_on);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -699,7 +699,7 @@ int greedy_sparse_t(const void* values, const int64_t* ei, const double* points,
     const size_t lds = (size_t)n * 15 + 64;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_greedy_sparse<H>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_greedy_sparse<H>, dim3((unsigned)num_maps), dim3(n > 2048 ? 1024 : 256), lds, stream, lj, lk,
+    hipLaunchKernelGGL(k_greedy_sparse<H>, dim3((unsigned)num_maps), dim3((n > 2048 || (n > 512 && num_maps <= 512)) ? 1024 : 256), lds, stream, lj, lk,
                        static_cast<const H*>(values), off, srtj, srte, len, uoff, points,
                        nb, tours, num_maps, n, E, mpi, reinterpret_cast<unsigned long long*>(err + 16));
     HIP_TRY(hipGetLastError());
