@@ -154,11 +154,13 @@ int tsp2opt_evaluate(const void* points, const int64_t* tours, double* lengths_o
  *   points    (num_instances, n, 2) double (the reference casts to double, greedy_search.py:15)
  *   tours_out (num_maps, n+1) int64: tour from node 0 back to node 0
  *   maps_per_instance  heat map k belongs to instance k / maps_per_instance (parallel_sampling)
- *   workspace at least tsp2opt_greedy_workspace_bytes(...) bytes, 256-byte aligned (holds the key
- *            matrices and the candidate lists)
+ *   workspace at least tsp2opt_greedy_workspace_bytes(...) bytes, 256-byte aligned (4 n^2 + 28 n bytes per
+ *            heat map: fp32 filter keys, candidate lists, neighbour table; unused for n <= 128)
  * Edges are taken in increasing order of -A_ij/|v_i-v_j| (double); exactly equal keys of different
  * edges are ordered by flat index i*n+j (the reference's order for ties is numpy's unstable argsort:
- * undefined).  n <= 10200 (the state of one heat map, 16 B per node, lives in the LDS of one wave).
+ * undefined).  Keys are compared as fp32 approximations with a margin and exactly (double) inside it: the
+ * tours are those of the exact order.  n <= 10200 (16-bit node ids; a heat map's merge state, 12 B per node,
+ * lives in the LDS of its workgroup).  Asynchronous on hip_stream.
  */
 int tsp2opt_greedy_decode(const void* heat, const double* points, int64_t* tours_out,
                           int64_t num_maps, int32_t n, int32_t maps_per_instance, int32_t heat_dtype,
