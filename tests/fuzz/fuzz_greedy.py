@@ -26,7 +26,10 @@ cases = fails = 0
 kinds = {}
 last = time.time()
 while time.time() < t_end:
-    n = int(rng.choice([rng.integers(2, 20), rng.integers(20, 130), rng.integers(130, 520), rng.integers(520, a.max_n + 1)]))
+    bands = [(2, 20), (20, 130), (130, 520), (520, a.max_n + 1)]
+    lo, hi = bands[int(rng.integers(0, len(bands)))]
+    hi = min(hi, a.max_n + 1)
+    n = int(rng.integers(min(lo, hi - 1), hi))
     inst, mpi = int(rng.integers(1, 4)), int(rng.integers(1, 4))
     dtype = np.float32 if rng.random() < 0.6 else np.float64
     layout = rng.choice(["uniform", "grid", "clustered", "coincident"])

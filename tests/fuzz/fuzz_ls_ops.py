@@ -24,7 +24,10 @@ t_end = time.time() + a.seconds
 cases = fails = 0
 stats = {}
 while time.time() < t_end:
-    n = int(rng.choice([rng.integers(3, 12), rng.integers(12, 90), rng.integers(90, a.max_n + 1)]))
+    bands = [(3, 12), (12, 90), (90, a.max_n + 1)]
+    lo, hi = bands[int(rng.integers(0, len(bands)))]
+    hi = min(hi, a.max_n + 1)
+    n = int(rng.integers(min(lo, hi - 1), hi))
     inst, tpi = int(rng.integers(1, 4)), int(rng.integers(1, 4))
     layout = rng.choice(["uniform", "grid", "clustered"])
     if layout == "grid":

@@ -30,8 +30,10 @@ stats = {}
 last = time.time()
 try:
     while time.time() < t_end:
-        n = int(rng.choice([rng.integers(2, 12), rng.integers(12, 130), rng.integers(130, 520),
-                            rng.integers(520, a.max_n + 1)]))
+        bands = [(2, 12), (12, 130), (130, 520), (520, a.max_n + 1)]
+        lo, hi = bands[int(rng.integers(0, len(bands)))]
+        hi = min(hi, a.max_n + 1)
+        n = int(rng.integers(min(lo, hi - 1), hi))
         dtype = np.float64 if rng.random() < 0.6 else np.float32
         layout = rng.choice(["uniform", "grid", "clustered", "duplicates", "offset"])
         inst = int(rng.integers(1, 4))
