@@ -279,7 +279,7 @@ int tsp2opt_debug_cluster_inc(int32_t on);
 /* Diagnostic tuning knobs (benchmark sweeps only): what = 0: threads per workgroup of the
  * one-workgroup-per-tour kernel (0 = automatic); what = 1: capacity of the cluster kernel's
  * changed-group list in sixteenths of all groups (default 13); what = 2: tiles a lane must own for the
- * tile-minimum cache to be used (default 2); what = 3: cluster kernel variant, 0 automatic, 1 band
+ * tile-minimum cache to be used (default 3); what = 3: cluster kernel variant, 0 automatic, 1 band
  * kernel only, 2 full-window kernel only; what = 4: changed-tile list capacity of the one-workgroup /
  * full-window kernels in sixteenths of the tiles (default 13); what = 5: unused LDS bytes added to the
  * one-workgroup kernel's request (lowers the workgroups resident per CU: occupancy sweeps; default 0);

@@ -18,7 +18,7 @@ for st in $STAGES; do
        python tools/summarize_pmc.py > $O/${TAG}_tsp500_pmc_summary.json || exit 1 ;;
   configs) for c in tsp50 tsp100 tsp1000 tsp10000; do
       echo "   bench $c"
-      timeout -k 10 250 python bench.py --config $c --steps 3 --warmup 1 > $O/${TAG}_bench_$c.json 2> $O/${TAG}_bench_$c.err || exit 1
+      timeout -k 10 250 python bench.py --config $c --steps 5 --warmup 2 > $O/${TAG}_bench_$c.json 2> $O/${TAG}_bench_$c.err || exit 1
     done ;;
   ktconfigs) for c in tsp100 tsp1000 tsp10000; do
       echo "   kernel trace $c"
