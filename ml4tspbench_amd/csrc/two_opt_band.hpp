@@ -306,17 +306,26 @@ __device__ __forceinline__ void sweep_c(const CView<T>& v, const CGeo& g, int ti
             __builtin_amdgcn_s_setprio(0);
             const int psh = __builtin_ctz((unsigned)g.K) - g.Psh;       // log2(parts per group)
             const unsigned items = nl << psh;
-            for (unsigned t = (unsigned)tid; t < items; t += (unsigned)g.nt) {
-                const int id = v.list[t >> psh];
-                const int u = id / g.NG, q = id - u * g.NG;
-                const float pm = part_min_c(v, g, u, q, (int)(t & ((1u << psh) - 1u)));
-                atomicMin(&v.Mc[q * units + u], fkey(pm));
+            // handed out 64 at a time from a counter: waves on a
+            // slower SIMD take fewer, nobody waits at the barrier for a wave that was dealt one round more
+            unsigned* next = &ctl->next_item;                          // starts at nt: the first batch is dealt
+            for (unsigned t0 = (unsigned)(tid & ~63); t0 < items;) {
+                const unsigned t = t0 + (unsigned)(tid & 63);
+                if (t < items) {
+                    const int id = v.list[t >> psh];
+                    const int u = id / g.NG, q = id - u * g.NG;
+                    const float pm = part_min_c(v, g, u, q, (int)(t & ((1u << psh) - 1u)));
+                    atomicMin(&v.Mc[q * units + u], fkey(pm));
+                }
+                if (items <= (unsigned)g.nt) break;
+                if ((tid & 63) == 0) t0 = atomicAdd(next, 64u);
+                t0 = (unsigned)__builtin_amdgcn_readfirstlane((int)t0);
             }
             __builtin_amdgcn_s_setprio(3);
         }
         FINE(pf, 1);
         __syncthreads();
-        if (tid == 0) ctl->nlist = 0;
+        if (tid == 0) { ctl->nlist = 0; ctl->next_item = (unsigned)g.nt; }
         if (!full) {
             a1 = INFINITY;
             a2 = INFINITY;
@@ -542,7 +551,7 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
 
     for (int64_t tk = cluster; tk < p.num_tours; tk += p.num_clusters) {
         __syncthreads();
-        if (tid == 0) ctl->nlist = 0;
+        if (tid == 0) { ctl->nlist = 0; ctl->next_item = (unsigned)nt; }
         const T* X = reinterpret_cast<const T*>(p.points) + (size_t)(tk / p.tpi) * (size_t)n * 2;
         int64_t* gt = p.tours + (size_t)tk * (size_t)(n + 1);
         // ---- stage + validate (every workgroup of the cluster computes the same flags) -------

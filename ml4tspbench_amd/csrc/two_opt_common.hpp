@@ -102,6 +102,7 @@ struct Ctl {                          // LDS control block (first bytes of dynam
     int pAmb[kMaxWaves];
     unsigned cand[kMaxCand];
     unsigned nlist;                   // changed tiles queued for this iteration
+    unsigned next_item;               // band kernel: next batch of changed-group parts to hand out
     int ambiguous;
     int tour_id;
     int flags;
