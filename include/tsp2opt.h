@@ -180,9 +180,11 @@ int64_t tsp2opt_greedy_workspace_bytes(int64_t num_maps, int32_t n, int32_t heat
  *              per call (num_instances = 1); a batch runs all its instances side by side
  *   points, tours_out, maps_per_instance: as tsp2opt_greedy_decode
  * Every node keeps the complete, exactly ordered list of its listed partners (workspace: 12 B per listed
- * edge and instance + 12 B per listed edge and heat map, instead of 8 n^2 per heat map); pairs that are not listed
- * all have the key -0.0 and are taken, after every listed edge, in flat-index order -- the tie rule of the
- * dense entry point and of the oracle (the reference's order among equal keys is numpy's unstable argsort).
+ * edge and instance + 12 B per listed edge and heat map, instead of 8 n^2 per heat map); pairs without a positive
+ * sum (not listed, or listed with zeros) all have the key -0.0 and are taken, after every listed edge, in
+ * flat-index order -- the tie rule of the dense entry point and of the oracle (the reference's order among equal
+ * keys is numpy's unstable argsort) -- and last of all, in the same order, those among them whose two points
+ * coincide (their key -0.0 / 0 is NaN, which numpy sorts last).
  * A listed pair whose heat sum is negative (its key would sort after the unlisted pairs) or a node with more
  * than 7000 listed edges gives TSP2OPT_E_UNSUPPORTED: densify and call tsp2opt_greedy_decode.  n <= 10900.
  * The call synchronises `hip_stream` (it reads back an error word).  Diagnostics of heat map 0 are left in

@@ -108,7 +108,7 @@ __device__ __forceinline__ void row_topk(float k0, unsigned j0, float k1, unsign
         if (__ballot(popped == 2)) break;               // somebody's next best is unknown
         const bool has = j0 != 0xffffu;
         const float hf = has ? k0 : INFINITY;
-        const float m = wave_min(hf);
+        const float m = wave_min_ordered(hf);           // (hf is a filter key or +inf, never NaN)
         const float hi = amb_hi(m);
         const bool in = has && hf <= hi;
         const unsigned long long bal = __ballot(in);
@@ -168,26 +168,29 @@ __global__ void __launch_bounds__(512) k_greedy_prepare(const H* __restrict__ A,
     }
     // software pipeline: the global loads of tile c0 + 64 (both operands) are in flight while tile c0
     // is computed
+    // (indices are clamped instead of predicated: what a lane loads for a row or column past n is never used)
     H a[4], tr[4];
-    auto load_tile = [&](int c0) {
-        const int j = c0 + x;
+    double pcx, pcy;                                    // the tile's column coordinates travel with it
+    const H* arow[4];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int i = i0 + y + 8 * rr;
-            a[rr] = (i < n && j < n) ? Ab[(size_t)i * n + j] : (H)0;
-        }
+    for (int rr = 0; rr < 4; ++rr) arow[rr] = Ab + (size_t)min(i0 + y + 8 * rr, n - 1) * n;
+    const int icl = min(i0 + (t & 31), n - 1);
+    auto load_tile = [&](int c0) {
+        const int j = min(c0 + x, n - 1);
+        pcx = P[2 * j];
+        pcy = P[2 * j + 1];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) a[rr] = arow[rr][j];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int c = (t >> 5) + 16 * k, r = t & 31;
-            const int jr = c0 + c, ic = i0 + r;
-            tr[k] = (jr < n && ic < n) ? Ab[(size_t)jr * n + ic] : (H)0;
+            const int jr = min(c0 + (t >> 5) + 16 * k, n - 1);
+            tr[k] = Ab[(size_t)jr * n + icl];
         }
     };
-    auto lessf = [](float k, unsigned j, float bk, unsigned bj) { return k < bk || (k == bk && j < bj); };
     load_tile(0);
     for (int c0 = 0; c0 < n; c0 += 64) {
         const int j = c0 + x;
-        const double cx = j < n ? P[2 * j] : 0.0, cy = j < n ? P[2 * j + 1] : 0.0;
+        const double cx = pcx, cy = pcy;
         H ac[4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) ac[rr] = a[rr];
@@ -203,14 +206,16 @@ __global__ void __launch_bounds__(512) k_greedy_prepare(const H* __restrict__ A,
                 if (j != i) {
                     const H s = ac[rr] + tile[x][r];
                     k = filter_key(s, rx[rr] - cx, ry[rr] - cy);
-                    if (lessf(k, (unsigned)j, b2k[rr], b2j[rr])) {
-                        if (lessf(k, (unsigned)j, b1k[rr], b1j[rr])) {
-                            b2k[rr] = b1k[rr]; b2j[rr] = b1j[rr];
-                            b1k[rr] = k; b1j[rr] = (unsigned)j;
-                        } else {
-                            b2k[rr] = k; b2j[rr] = (unsigned)j;
-                        }
-                    }
+                    // a lane meets its columns in increasing order, so (k, j) precedes a tracked entry exactly
+                    // when k is smaller, or the slot is empty (key +inf, index 0xffff: every index precedes
+                    // it); selects instead of branches: a lane sees n / 64 entries per row and most of the
+                    // first ones enter
+                    const bool lt1 = k < b1k[rr] || b1j[rr] == 0xffffu;
+                    const bool lt2 = k < b2k[rr] || b2j[rr] == 0xffffu;
+                    b2k[rr] = lt1 ? b1k[rr] : lt2 ? k : b2k[rr];
+                    b2j[rr] = lt1 ? b1j[rr] : lt2 ? (unsigned)j : b2j[rr];
+                    b1k[rr] = lt1 ? k : b1k[rr];
+                    b1j[rr] = lt1 ? (unsigned)j : b1j[rr];
                 }
                 Kb[(size_t)i * n + j] = k;
             }
@@ -291,7 +296,7 @@ template <typename H>
 __device__ __forceinline__ void rescan_finish(const RLds& L, const RowCtx<H>& C, int i, int oe, float b1k, unsigned b1j,
                                               float b2k, int lane)
 {
-    const float m = wave_min(b1j != 0xffffu ? b1k : INFINITY);
+    const float m = wave_min_ordered(b1j != 0xffffu ? b1k : INFINITY);
     const float hi = amb_hi(m);
     const unsigned long long e1 = __ballot(b1j != 0xffffu && b1k <= hi);
     const unsigned long long e2 = __ballot(b1j != 0xffffu && b2k <= hi);
@@ -535,7 +540,7 @@ __global__ void __launch_bounds__(1024) k_greedy(const float* __restrict__ Kd, c
                 const float k = L.key[i];
                 if (k == k) lm = fminf(lm, k);
             }
-            lm = wave_min(lm);
+            lm = wave_min_ordered(lm);
             if (lane == 0) red_f[wv] = lm;
             __syncthreads();
             float m = INFINITY;
@@ -867,7 +872,7 @@ __global__ void __launch_bounds__(256) k_greedy_small(const H* __restrict__ A, c
                 const float k = L.key[i];
                 if (k == k) lm = fminf(lm, k);
             }
-            lm = wave_min(lm);
+            lm = wave_min_ordered(lm);
             if (lane == 0) red_f[wv] = lm;
             __syncthreads();
             float m = INFINITY;

@@ -17,10 +17,10 @@
 // still-valid edge" over the nodes' current candidates is the edge the sorted scan would insert next, an
 // invalidated candidate is replaced by the next valid entry of the node's list, and edges whose turn nothing
 // can disturb are inserted many per round (see k_greedy_sparse).
-// When no listed edge is valid any more, every remaining pair has S = 0, i.e. the same key -0.0, and
-// the reference's order among them is numpy's unstable argsort (undefined); like the dense path and
-// the oracle, the lower flat index i*n + j wins: the smallest node that is still a fragment end takes
-// its smallest valid partner, until one path is left.  Negative sums (keys that would sort AFTER the
+// When no listed edge is valid any more, every remaining pair has S = 0, i.e. the same key -0.0 (NaN, which
+// sorts last, where the two points coincide), and the reference's order among them is numpy's unstable
+// argsort (undefined); like the dense path and the oracle, the lower flat index i*n + j wins: the smallest
+// node that is still a fragment end takes its smallest valid partner, until one path is left.  Negative sums (keys that would sort AFTER the
 // zeros) are reported (TSP2OPT_E_UNSUPPORTED) so that the caller can take the dense path.
 //
 // Workspace: 12 B per listed edge and instance for the sorted rows + 12 B per listed edge and heat map for
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(1024) k_greedy_sparse(const uint16_t* __restri
                 const float k = L.key[i];
                 if (k == k) lm = fminf(lm, k);
             }
-            lm = wave_min(lm);
+            lm = wave_min_ordered(lm);
             if (lane == 0) red_f[wv] = lm;
             __syncthreads();
             float m = INFINITY;
@@ -533,32 +533,47 @@ __global__ void __launch_bounds__(1024) k_greedy_sparse(const uint16_t* __restri
     }
     __syncthreads();
     if (tid >= 64) return;                              // the rest is short and serial: wave 0
-    // ---- unlisted pairs: all have the key -0.0, the lower flat index i*n + j goes first: the smallest
-    // fragment end takes its smallest valid partner.  Both only ever move up: i is the smallest open node (it
-    // stays open after its first unlisted merge when it had degree 0), its partner is the smallest open node
-    // above it other than its own far end, so one ascending sweep over the open nodes serves all merges.
+    // ---- the pairs without a positive sum.  Their key is -0.0 / d: -0.0, all tied, the lower flat index
+    // i*n + j first -- except where d is not a positive number (coincident points, squares that underflow,
+    // NaN coordinates): there it is NaN, which numpy sorts after everything else (tied again, by index).  Two
+    // passes, zero keys then NaN keys; in each the smallest open node that still has a partner of the pass
+    // takes its smallest one.  Both only ever move up: a node left without a partner stays without one for the
+    // rest of the pass (open nodes only disappear, and a fragment's new far end was open before), so one
+    // ascending sweep over the open nodes serves all merges of a pass.
     const unsigned long long t2 = wall_clock64();
     const int listed_merges = merges;
-    {
-        int i = -1, gi = 0;                             // current smallest open node and the group scan position
+    for (int pass = 0; pass < 2 && merges < n - 1; ++pass) {
+        int i = -1, from = 0;                           // current node; nodes below `from` are done for this pass
         while (merges < n - 1) {
-            if (i < 0 || L.deg[i] >= 2) {               // (re)locate the smallest open node
+            if (i < 0 || L.deg[i] >= 2) {               // (re)locate the smallest open node at or above `from`
                 i = -1;
-                for (; gi < G; ++gi) {
-                    const int k = (gi << 6) + lane;
-                    const unsigned long long bal = __ballot(k < n && L.deg[k] < 2);
-                    if (bal) { i = (gi << 6) + __ffsll((long long)bal) - 1; break; }
+                for (int g = from >> 6; g < G; ++g) {
+                    const int k = (g << 6) + lane;
+                    const unsigned long long bal = __ballot(k < n && k >= from && L.deg[k] < 2);
+                    if (bal) { i = (g << 6) + __ffsll((long long)bal) - 1; break; }
                 }
                 if (i < 0) break;
+                from = i;
             }
             const int oe = L.oend[i];
+            const double xi = M.P[2 * i], yi = M.P[2 * i + 1];
             int j = -1;
-            for (int g = i >> 6; g < G; ++g) {
+            for (int g = i >> 6; g < G && j < 0; ++g) {
                 const int k = (g << 6) + lane;
-                const unsigned long long bal = __ballot(k < n && L.deg[k] < 2 && k != i && !(k == oe && oe != i));
-                if (bal) { j = (g << 6) + __ffsll((long long)bal) - 1; break; }
+                unsigned long long bal = __ballot(k < n && k > i && L.deg[k] < 2 && !(k == oe && oe != i));
+                while (bal) {                           // (wave-uniform: every lane tests the same candidate)
+                    const int c = (g << 6) + __ffsll((long long)bal) - 1;
+                    bal &= bal - 1;
+                    const double dx = xi - M.P[2 * c], dy = yi - M.P[2 * c + 1];
+                    const bool nankey = !(dx * dx + dy * dy > 0.0);     // sqrt(0) = 0 and -0.0 / 0 is NaN
+                    if (nankey == (pass == 1)) { j = c; break; }
+                }
             }
-            if (j < 0) break;                           // cannot happen while two fragments remain
+            if (j < 0) {                                // nothing for i in this pass: on to the next open node
+                from = i + 1;
+                i = -1;
+                continue;
+            }
             if (lane == 0) sp_link(L, nb, i, j);
             ++merges;
             __builtin_amdgcn_wave_barrier();

@@ -218,23 +218,6 @@ __device__ __forceinline__ float funkey(unsigned k)
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned umin_step(unsigned v)
-{
-    const unsigned o = (unsigned)dpp_i<CTRL, ROW_MASK>((int)v);
-    return o < v ? o : v;
-}
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
-{
-    v = umin_step<0xB1, 0xf>(v);
-    v = umin_step<0x4E, 0xf>(v);
-    v = umin_step<0x141, 0xf>(v);
-    v = umin_step<0x140, 0xf>(v);
-    v = umin_step<0x142, 0xa>(v);
-    v = umin_step<0x143, 0xc>(v);
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 // full sweep of the lane's own unit: every tile minimum to Mc, the unit minimum to Mu
 template <int Q, bool CL, typename T>
 __device__ __forceinline__ void filter_sweep_cached(const View<T>& v, const Geo& g, int tid)

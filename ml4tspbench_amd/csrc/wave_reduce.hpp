@@ -59,6 +59,37 @@ __device__ __forceinline__ float wave_min(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// unsigned minimum over the wave.  Masked-off lanes read the identity, which lets the compiler fold the move
+// into v_min_u32_dpp: one instruction a step.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned umin_step(unsigned v)
+{
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return o < v ? o : v;
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    v = umin_step<0xB1, 0xf>(v);
+    v = umin_step<0x4E, 0xf>(v);
+    v = umin_step<0x141, 0xf>(v);
+    v = umin_step<0x140, 0xf>(v);
+    v = umin_step<0x142, 0xa>(v);
+    v = umin_step<0x143, 0xc>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// wave_min for values that are never NaN, on their order-preserving integer images (fminf quiets both operands
+// first: four instructions a step)
+__device__ __forceinline__ float wave_min_ordered(float v)
+{
+    unsigned u = (unsigned)__float_as_int(v);
+    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+    u = wave_min_u32(u);
+    u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
+    return __int_as_float((int)u);
+}
+
 // inclusive prefix sum over the wave (Hillis-Steele inside the rows of 16 lanes on row_shr, then the
 // row totals on row_bcast15 / row_bcast31); lanes without a source add 0
 template <int CTRL, int ROW_MASK>

@@ -18,6 +18,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--max-n", type=int, default=700)
+ap.add_argument("--only-case", type=int, default=0, help="replay the random stream and run this case alone, verbosely")
+ap.add_argument("--dump", default="", help="with --only-case: save the case's inputs to this .npz")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 dev = torch.device("cuda", 0)
@@ -25,7 +27,7 @@ t_end = time.time() + a.seconds
 cases = fails = 0
 kinds = {}
 last = time.time()
-while time.time() < t_end:
+while time.time() < t_end or (a.only_case and cases < a.only_case):
     bands = [(2, 20), (20, 130), (130, 520), (520, a.max_n + 1)]
     lo, hi = bands[int(rng.integers(0, len(bands)))]
     hi = min(hi, a.max_n + 1)
@@ -63,11 +65,25 @@ while time.time() < t_end:
         vals = (rng.random((B, ei.shape[2])) + 0.01).astype(dtype)
         if rng.random() < 0.3:
             vals[:, rng.integers(0, vals.shape[1], size=5)] = 0
+        # twin points whose pair has no positive sum: the key is -0.0 / 0 = NaN and sorts last (a generator of its
+        # own, so that the main stream -- and with it every recorded seed -- stays what it was)
+        if layout == "coincident" and np.random.default_rng([a.seed, cases]).random() < 0.5:
+            for q in range(inst):
+                twin = (d[q][ei[q, 0], ei[q, 1]] == 0) & (ei[q, 0] != ei[q, 1])
+                vals[q * mpi:(q + 1) * mpi, twin] = 0
+        if a.only_case and cases + 1 != a.only_case:
+            cases += 1
+            continue
         dense = np.stack([greedy_oracle.densify(vals[m:m + 1], ei[m // mpi], n)[0] for m in range(B)])
         ref = np.concatenate([greedy_oracle.greedy(pts[m // mpi], dense[m:m + 1]) for m in range(B)])
         got_s = amd.greedy_decode_sparse_device(torch.from_numpy(vals).to(dev), torch.from_numpy(ei).to(dev),
                                                 torch.from_numpy(pts).to(dev), maps_per_instance=mpi).cpu().numpy()
         ok &= bool(np.array_equal(got_s, ref))
+        if a.only_case:
+            print("sparse decoder == oracle:", bool(np.array_equal(got_s, ref)), "maps that differ:",
+                  [int(m) for m in range(B) if not np.array_equal(got_s[m], ref[m])])
+            if a.dump:
+                np.savez(a.dump, pts=pts, vals=vals, ei=ei, ref=ref, got_sparse=got_s, mpi=mpi)
         heat = dense
     else:
         if kind == "near_ties":
@@ -77,15 +93,25 @@ while time.time() < t_end:
             heat = rng.random((B, n, n)).astype(dtype)
             if kind == "thresholded":
                 heat[heat < rng.uniform(0.3, 0.95)] = 0
+        if a.only_case and cases + 1 != a.only_case:
+            cases += 1
+            continue
         ref = np.concatenate([greedy_oracle.greedy(pts[m // mpi], heat[m:m + 1]) for m in range(B)])
     got = amd.greedy_decode_device(torch.from_numpy(np.ascontiguousarray(heat)).to(dev), torch.from_numpy(pts).to(dev),
                                    maps_per_instance=mpi).cpu().numpy()
     ok &= bool(np.array_equal(got, ref))
+    if a.only_case:
+        print("dense decoder == oracle:", bool(np.array_equal(got, ref)), "maps that differ:",
+              [int(m) for m in range(B) if not np.array_equal(got[m], ref[m])])
+        if a.dump and kind != "knn":
+            np.savez(a.dump, pts=pts, heat=heat, ref=ref, got=got, mpi=mpi)
     cases += 1
     if not ok:
         fails += 1
         print(json.dumps({"mismatch": {"n": n, "inst": inst, "mpi": mpi, "dtype": str(np.dtype(dtype)), "layout": str(layout),
                                        "kind": str(kind), "case": cases, "seed": a.seed}}), flush=True)
+    if a.only_case and cases >= a.only_case:
+        break
     if time.time() - last > 30:
         print(f"... {cases} cases, {fails} mismatches", file=sys.stderr, flush=True)
         last = time.time()

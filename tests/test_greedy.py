@@ -236,6 +236,41 @@ def test_gpu_sparse_greedy_matches_oracle_and_dense_path(n, k, maps, dtype, dup)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,k,twins,listed", [(22, 2, 1, True), (22, 2, 1, False), (90, 3, 4, True), (300, 5, 9, False),
+                                              (70, 2, 30, False)])
+def test_gpu_sparse_greedy_coincident_points_with_zero_sum(n, k, twins, listed):
+    """A pair of coincident points without a positive sum has the key -0.0 / 0 = NaN, which numpy sorts after the
+    zero keys of all the other unlisted pairs (found by tests/fuzz/fuzz_greedy.py, seed 303 case 1520: the twin
+    pair was listed with two zero values).  `listed`: the twin pairs stay in the list with zero values;
+    otherwise they are not listed at all."""
+    from ml4tspbench_amd import greedy_decode_device, greedy_decode_sparse_device
+    from oracle import greedy_oracle
+    rng = np.random.default_rng(n + 7 * twins)
+    pts = rng.random((n, 2))
+    pairs = rng.permutation(n)[:2 * twins].reshape(twins, 2)
+    pts[pairs[:, 1]] = pts[pairs[:, 0]]
+    d = ((pts[:, None] - pts[None]) ** 2).sum(-1)
+    nn = np.argsort(d, axis=1, kind="stable")[:, :k]
+    e0, e1 = np.repeat(np.arange(n), k), nn.reshape(-1)
+    twin = (d[e0, e1] == 0) & (e0 != e1)
+    assert twin.any()
+    if not listed:
+        e1 = np.where(twin, e0, e1)                         # the twin's slot becomes one more self loop
+    ei = np.stack([e0, e1]).astype(np.int64)
+    vals = (rng.random((2, ei.shape[1])) + 0.01).astype(np.float32)
+    vals[:, twin] = 0
+    dev = torch.device("cuda", 0)
+    got = greedy_decode_sparse_device(torch.from_numpy(vals).to(dev), torch.from_numpy(ei).to(dev),
+                                      torch.from_numpy(pts).to(dev)[None], maps_per_instance=2).cpu().numpy()
+    dense = greedy_oracle.densify(vals, ei, n)
+    ref = greedy_oracle.greedy(pts, dense)
+    assert np.array_equal(got, ref)
+    d_got = greedy_decode_device(torch.from_numpy(dense).to(dev), torch.from_numpy(pts).to(dev)[None],
+                                 maps_per_instance=2).cpu().numpy()
+    assert np.array_equal(d_got, ref)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_gpu_sparse_greedy_batch_of_instances(dtype):
     """One call, one edge list per instance (equal lengths), maps_per_instance heat maps each: every map equals
