@@ -23,6 +23,7 @@ dev = torch.device("cuda", 0)
 t_end = time.time() + a.seconds
 cases = fails = 0
 stats = {}
+last = time.time()
 while time.time() < t_end:
     bands = [(3, 12), (12, 90), (90, a.max_n + 1)]
     lo, hi = bands[int(rng.integers(0, len(bands)))]
@@ -67,5 +68,8 @@ while time.time() < t_end:
         fails += 1
         print(json.dumps({"mismatch": {"n": n, "inst": inst, "tpi": tpi, "layout": str(layout), "kind": str(kind),
                                        "case": cases, "seed": a.seed}}), flush=True)
+    if time.time() - last > 30:
+        print(f"... {cases} cases, {fails} mismatches", file=sys.stderr, flush=True)
+        last = time.time()
 print(json.dumps({"cases": cases, "mismatches": fails, "seed": a.seed, "by_kind": stats}))
 sys.exit(1 if fails else 0)
