@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the batched 2-opt hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config tsp500|tsp100|tsp1000|tsp50]
-                    [--mode independent|grouped] [--dtype f64|f32] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config tsp500|tsp100|tsp1000|tsp50|tsp10000]
+                    [--mode independent|grouped] [--dtype f64|f32] [--no-cpu] [--no-configs]
 
 One "step" = one pass of the hot path over one batch of synthetic input: ALL tours of the batch are
 driven to their 2-opt local optimum by one tsp2opt_solve call (default workload: BASELINE.json
@@ -14,6 +14,16 @@ collective) and the timed region ends with one all_gather of tours + lengths.
 
 metric: pair-deltas/s = sum over tours of sweeps * (N-1)(N-2)/2 / wall time, sweeps = iterator+1
 when converged else the cap.  Prints ONE JSON line on rank 0.
+
+The default invocation (no --config) times the headline exactly as above (W warm-up steps, K timed
+steps, top-level keys) and then, outside that timed region, adds to the SAME line:
+  "configs": the other four BASELINE.json configurations, 3 timed steps each, with their own roofline
+             objects, plus two more start-tour variants of configs[2] (heat-map-weighted sampled starts,
+             ml4tsp/nar/decoder/sampling.py:21-43, and greedy-decoded starts) with tours/s;
+  "strong":  (--gpus N > 1, or under torch.distributed.run) BASELINE.json configs[2] as it is worded --
+             ONE batch of 128 instances x 16 tours sharded over the N ranks by sharding.solve_sharded,
+             final all_gather included;
+  "cpu_baseline": the CPU port on the box's cores (N = 1 only), with a "single_core" leg.
 """
 from __future__ import annotations
 
@@ -41,6 +51,10 @@ CONFIGS = {
 FLOP_PER_PAIR = 15.0          # 2 x (2 sub + 2 mul + add + sqrt) + 3 add/sub
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
 PEAK_FP64_VALU_TFLOPS = 78.6   # SURVEY.md 8(d3) / BASELINE.md: the fp64 vector peak
+# DESIGN.md 4.2 (tools/valu_chain_microbench.hip): SIMD cycles per 64 evaluated pairs of the fully packed
+# per-pair chain (1 v_sqrt_f32, packed sub / mul / fma / add, min) -- the instruction floor of the sweep
+INSN_FLOOR_CYCLES_PER_64_PAIRS = 25.4
+SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 
 def lib_sha256() -> str:
@@ -108,15 +122,71 @@ def make_heat(pts: torch.Tensor, per: int, knn: int, seed: int) -> torch.Tensor:
     return out
 
 
-def cpu_baseline(name: str, pts: np.ndarray, tours: np.ndarray, tpi: int, group: int, cap: int):
+def sampled_start_tours(heat: torch.Tensor, seed: int) -> torch.Tensor:
+    """Heat-map-weighted sequential sampling of start tours, batched on the device: the procedure of
+    ml4tsp/nar/decoder/sampling.py:21-43 (start at node 0; the next node is drawn with probability
+    proportional to the current node's heat-map row over the nodes not yet visited).  heat (B, N, N) ->
+    (B, N+1) int64.  Input generator of the bench, not part of the timed path."""
+    B, n, _ = heat.shape
+    g = torch.Generator(device=heat.device)
+    g.manual_seed(seed)
+    tours = torch.zeros((B, n + 1), dtype=torch.int64, device=heat.device)
+    open_ = torch.ones((B, n), dtype=torch.float32, device=heat.device)
+    open_[:, 0] = 0
+    cur = torch.zeros(B, dtype=torch.int64, device=heat.device)
+    rows = torch.arange(B, device=heat.device)
+    for k in range(1, n):
+        w = heat[rows, cur] * open_ + 1e-30 * open_            # a row without heat left: uniform over the open nodes
+        cur = torch.multinomial(w, 1, generator=g).squeeze(1)
+        tours[:, k] = cur
+        open_[rows, cur] = 0
+    return tours
+
+
+def cpu_model() -> str:
+    """Model string of the host CPU as the OS reports it, with family / model / stepping (virtualised
+    boxes often mask the SKU in `model name`; the numeric ids still identify the part)."""
+    name, fam, model, step = "unknown", "", "", ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                key, _, val = line.partition(":")
+                key, val = key.strip(), val.strip()
+                if key == "model name" and name == "unknown":
+                    name = val
+                elif key == "cpu family" and not fam:
+                    fam = val
+                elif key == "model" and not model:
+                    model = val
+                elif key == "stepping" and not step:
+                    step = val
+                elif key == "processor" and val != "0":
+                    break
+    except OSError:
+        pass
+    ids = f"family {fam} model {model} stepping {step}" if fam else ""
+    # AMD family 25 = Zen 3 / Zen 4 (model 1: EPYC 7003 Milan, 17: EPYC 9004 Genoa, 160: 97x4 Bergamo),
+    # family 26 = Zen 5 (model 2: EPYC 9005 Turin, 17: Turin Dense)
+    part = {("25", "1"): "Zen 3, EPYC 7003 'Milan'", ("25", "17"): "Zen 4, EPYC 9004 'Genoa'",
+            ("25", "160"): "Zen 4c, EPYC 97x4 'Bergamo'", ("26", "2"): "Zen 5, EPYC 9005 'Turin'",
+            ("26", "17"): "Zen 5c, EPYC 9005 'Turin Dense'"}.get((fam, model))
+    if part and "AMD" in name:
+        ids += f": {part}"
+    return f"{name} ({ids})" if ids else name
+
+
+def cpu_baseline(name: str, pts: np.ndarray, tours: np.ndarray, tpi: int, group: int, cap: int,
+                 max_threads: int):
     """The oracle (oracle/two_opt_oracle.c, a port of the reference algorithm) timed on this box's
     host cores on a bounded sample of the same workload (about 20 s of CPU work): the first `want`
     tours, and for sizes where even one tour per core exceeds the budget (TSP-10000) also a lower
-    iteration cap.  Returns the baseline dict, the oracle's tours/iterations and the cap it ran with."""
+    iteration cap.  BASELINE.md 2 / SURVEY 8 d4 ask for two legs: OpenMP over tours on the box's cores
+    (the dict itself) and one core (`single_core`, about 2 s of the same sample).
+    Returns the baseline dict, the oracle's tours/iterations and the cap it ran with."""
     from oracle import two_opt_oracle as orc
     n = pts.shape[1]
-    # 16 = the CPU share of a one-GPU box in this pool (its os.cpu_count() shows the whole machine)
-    threads = max(1, min(16, os.cpu_count() or 1, orc.max_threads()))
+    # default 16 = the CPU share of a one-GPU box in this pool (its os.cpu_count() shows the whole machine)
+    threads = max(1, min(max_threads, os.cpu_count() or 1, orc.max_threads()))
     pairs = (n - 1) * (n - 2) // 2
     budget = 20.0 * 3.0e8 * threads                  # ~3e8 pair evaluations per core-second
     est_sweeps = min(cap, int(n * 1.3) + 1)
@@ -134,6 +204,17 @@ def cpu_baseline(name: str, pts: np.ndarray, tours: np.ndarray, tpi: int, group:
                                    max_iterations=cpu_cap, threads=threads)
     dt = time.perf_counter() - t0
     capnote = "" if cpu_cap == cap else f", iteration cap lowered to {cpu_cap} for the sample"
+    # single core: whole groups from the front of the same sample, about 2 s of work
+    one = int(max(1, min(want, 2.0 * 5.0e8 / (pairs * min(cpu_cap, est_sweeps)))))
+    one = min(want, max(group, (one // group) * group))
+    t1 = time.perf_counter()
+    out1, it1, sw1 = orc.solve(pts[: (one + tpi - 1) // tpi], tours[:one], tours_per_instance=tpi,
+                               group_size=group, max_iterations=cpu_cap, threads=1)
+    dt1 = time.perf_counter() - t1
+    single = {"value": float(sw1.astype(np.int64).sum()) * pairs / dt1, "unit": "pair-deltas/s", "cores": 1,
+              "sample": f"first {one} tours of the same batch{capnote}, {dt1:.1f} s",
+              "tours_per_s": one / dt1 if cpu_cap == cap else None,
+              "matches_threaded_run": bool(np.array_equal(out1, out[:one]) and np.array_equal(it1, iters[:one]))}
     return {
         "value": float(sweeps.astype(np.int64).sum()) * pairs / dt,
         "unit": "pair-deltas/s",
@@ -143,18 +224,8 @@ def cpu_baseline(name: str, pts: np.ndarray, tours: np.ndarray, tpi: int, group:
         "sample": f"first {want} of {len(tours)} tours of the same batch{capnote}, {dt:.1f} s, "
                   f"{want / dt:.2f} tours/s, OpenMP over tours",
         "tours_per_s": want / dt if cpu_cap == cap else None,
+        "single_core": single,
     }, out, iters, cpu_cap
-
-
-def cpu_model() -> str:
-    try:
-        with open("/proc/cpuinfo") as fh:
-            for line in fh:
-                if line.startswith("model name"):
-                    return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
 
 
 def dense_torch_baseline(pts: np.ndarray, tours: np.ndarray, tpi: int, budget_s: float = 4.0):
@@ -190,6 +261,130 @@ def dense_torch_baseline(pts: np.ndarray, tours: np.ndarray, tpi: int, budget_s:
             "sample": f"{len(t)} tours of one instance, {it} iterations, {dt:.1f} s"}
 
 
+class Harness:
+    """Timing of one batch shape: W untimed + K timed steps back to back, bracketed by a device
+    synchronisation (and a barrier across ranks), MAX over ranks, HIP-event kernel times read afterwards."""
+
+    def __init__(self, dev, local_rank, dist, world, rank):
+        self.dev, self.local_rank, self.dist, self.world, self.rank = dev, local_rank, dist, world, rank
+        from ml4tspbench_amd import _lib
+        self.L = _lib.lib()
+
+    def fence(self):
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def time_steps(self, step, steps: int, warmup: int):
+        res = None
+        for _ in range(warmup):
+            res = step()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):      # back to back, no host synchronisation inside the timed region
+            res = step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        kern_ms = []
+        for back in range(min(steps, 64)):      # HIP events of the timed steps, read afterwards
+            m, f = ctypes.c_double(), ctypes.c_double()
+            if self.L.tsp2opt_profile_history_ms(self.local_rank, back, ctypes.byref(m), ctypes.byref(f)) == 0:
+                kern_ms.append(m.value + f.value)
+        if self.dist is not None:
+            tdt = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            self.dist.all_reduce(tdt, op=self.dist.ReduceOp.MAX)
+            dt = float(tdt.item())
+        return res, dt, (float(np.mean(kern_ms)) if kern_ms else None)
+
+    def totals(self, sweeps: torch.Tensor, iters: torch.Tensor, pairs: int, local_T: int):
+        """Whole-job sums over the ranks: pair-deltas per step, tours, iterations (sum, max)."""
+        v = torch.tensor([float(sweeps.to(torch.int64).sum().item()) * pairs, float(local_T),
+                          float(iters.sum().item()), float(iters.max().item()) if local_T else 0.0],
+                         dtype=torch.float64, device=self.dev)
+        if self.dist is not None:
+            mx = v[3:].clone()
+            self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM)
+            self.dist.all_reduce(mx, op=self.dist.ReduceOp.MAX)
+            v[3] = mx[0]
+        return [float(x) for x in v.tolist()]
+
+
+def kernel_of(n: int, T: int, dtype: str, device: int = 0) -> str:
+    """Name of the kernel variant the library picks for this shape (tsp2opt_plan / tsp2opt_cluster_plan)."""
+    from ml4tspbench_amd import _lib
+    code = _lib.DTYPE_F64 if dtype == "f64" else _lib.DTYPE_F32
+    cp = _lib.cluster_plan(n, code, T)
+    if cp["workgroups_per_tour"] >= 2:
+        kind = "full-window cluster" if cp["row_bands"] == 0 else "band cluster"
+        return f"{'k_two_opt' if cp['row_bands'] == 0 else 'k_two_opt_cluster'} ({cp['workgroups_per_tour']} workgroups of {cp['threads']} threads per tour, {kind})"
+    p = _lib.plan(n, code, device)
+    return f"k_two_opt (one workgroup of {p['threads']} threads per tour, {p['workgroups_per_cu']} per CU)"
+
+
+def simple_roofline(pair_deltas_rank0: float, kernel_ms, kernel: str):
+    if not kernel_ms:
+        return None
+    ach = pair_deltas_rank0 * FLOP_PER_PAIR / (kernel_ms * 1e-3) / 1e12
+    return {"bound": "valu", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_FP32_VALU_TFLOPS, "frac_fp64_peak": ach / PEAK_FP64_VALU_TFLOPS,
+            "kernel": kernel, "kernel_ms": kernel_ms, "traffic": None,
+            "note": "reference-equivalent work (see the headline's roofline.note); no PMC pass for this shape"}
+
+
+def run_extra_config(h: Harness, name: str, steps: int, seed: int, cap: int, start: str = "random"):
+    """One of the other BASELINE.json configurations (or another start-tour variant of configs[2]):
+    1 warm-up + `steps` timed steps, weak scaling when several ranks run it.  Returns the sub-object."""
+    import ml4tspbench_amd as amd
+    n, inst, tpi = CONFIGS[name]
+    pairs = (n - 1) * (n - 2) // 2
+    pts, tours, tpi = make_batch(name, seed + h.rank, np.float64)
+    d_pts = torch.from_numpy(pts).to(h.dev)
+    extra = {}
+    if start == "random":
+        d_tours = torch.from_numpy(tours).to(h.dev)
+        what = "random start tours"
+    else:
+        heat = make_heat(d_pts, tpi, 0, seed + h.rank)
+        if start == "sampled":
+            d_tours = sampled_start_tours(heat, seed + h.rank)
+            what = "heat-map-weighted sampled start tours (ml4tsp/nar/decoder/sampling.py:21-43, synthetic heat maps)"
+        else:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            amd.greedy_decode_device(heat, d_pts, maps_per_instance=tpi)
+            ev[0].record()
+            d_tours = amd.greedy_decode_device(heat, d_pts, maps_per_instance=tpi)
+            ev[1].record()
+            torch.cuda.synchronize()
+            extra["greedy_decode_ms"] = ev[0].elapsed_time(ev[1])
+            what = "greedy edge-merge decoded start tours (search/greedy_search.py:19-74, synthetic heat maps)"
+        del heat
+    T = d_tours.shape[0]
+
+    def step():
+        return amd.two_opt_device(d_pts, d_tours, tours_per_instance=tpi, group_size=1,
+                                  max_iterations=cap, want_lengths=True)
+
+    res, dt, kern_ms = h.time_steps(step, steps, 1)
+    status = res.status.cpu().numpy()
+    assert (status & (15 | 64)).max(initial=0) == 0, f"{name}: input rejected"
+    my_pd = float(res.sweeps.to(torch.int64).sum().item()) * pairs
+    pd, tours_total, it_sum, it_max = h.totals(res.sweeps, res.iterations, pairs, T)
+    ev = amd.evaluate_tours(d_pts, res.tours, tours_per_instance=tpi)
+    ok = bool(((ev.valid & 3) == 3).all().item())
+    out = {"name": name if start == "random" else f"{name}_{start}_start",
+           "workload": f"TSP-{n} uniform, {inst} instances x {tpi} {what} per GPU, 2-opt to local optimum, "
+                       f"max_iterations {cap}, independent termination",
+           "steps": steps, "warmup": 1, "ms_per_step": dt / steps * 1e3, "value": pd * steps / dt,
+           "unit": "pair-deltas/s", "tours_per_s": tours_total * steps / dt,
+           "mean_iterations": it_sum / tours_total, "max_iterations_seen": it_max,
+           "all_tours_valid": ok, "mean_length": float(res.lengths.mean().item()),
+           "kernel": kernel_of(n, T, "f64", h.local_rank), "kernel_ms": kern_ms,
+           "roofline": simple_roofline(my_pd, kern_ms, "k_two_opt" if n < 5000 else "k_two_opt_cluster")}
+    out.update(extra)
+    return out
+
+
 def main():
     # stdout carries exactly ONE line, the JSON: everything else that libraries print there (RCCL's
     # version banner at communicator creation, for one) is sent to stderr until the line is due
@@ -200,11 +395,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="tsp500", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="time this configuration only (default: tsp500 as the headline + the others in `configs`)")
     ap.add_argument("--mode", default="independent", choices=["independent", "grouped"])
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--max-iterations", type=int, default=5000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="headline only: skip the `configs` / `strong` sub-objects")
+    ap.add_argument("--config-steps", type=int, default=3, help="timed steps of every entry of `configs`")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="threads of the CPU baseline's OpenMP leg (default 16 = the CPU share of a one-GPU box)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank solves its own batch; strong: ONE batch (BASELINE.json configs[2]: "
                          "128 instances x 16 tours) sharded over the ranks by sharding.solve_sharded")
@@ -213,6 +413,11 @@ def main():
     ap.add_argument("--cluster-mode", type=int, default=-1,
                     help="diagnostic: -1 automatic, 0 one workgroup per tour, k>=2 up to k workgroups per tour")
     args = ap.parse_args()
+    diagnostic = bool(args.tune) or args.cluster_mode != -1 or args.instances > 0
+    all_configs = (args.config is None and not args.no_configs and not diagnostic
+                   and args.mode == "independent" and args.dtype == "f64" and args.scaling == "weak")
+    if args.config is None:
+        args.config = "tsp500"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -242,6 +447,7 @@ def main():
     for kv in args.tune:                             # diagnostic knobs, e.g. --tune 0=1024
         k_, v_ = kv.split("=")
         L.tsp2opt_debug_tune(int(k_), int(v_))
+    h = Harness(dev, local_rank, dist if use_dist else None, world, rank)
 
     np_dtype = np.float64 if args.dtype == "f64" else np.float32
     if args.instances > 0:
@@ -261,11 +467,11 @@ def main():
         gather_t = torch.empty((world * T, pack_tours(d_tours[:1]).shape[1]), dtype=torch.uint8, device=dev)
         gather_l = torch.empty(world * T, dtype=torch.float64, device=dev)
 
-    def step_strong():
+    def step_strong(p=None, t=None):
         # the tested function is the timed one: contiguous instance blocks per rank, one final all_gather
         from ml4tspbench_amd.sharding import solve_sharded
-        return solve_sharded(d_pts, d_tours, tours_per_instance=tpi, group_size=group,
-                             max_iterations=args.max_iterations, want_result=True)
+        return solve_sharded(d_pts if p is None else p, d_tours if t is None else t, tours_per_instance=tpi,
+                             group_size=group, max_iterations=args.max_iterations, want_result=True)
 
     def step():
         if strong:
@@ -278,30 +484,7 @@ def main():
             res.all_tours = unpack_tours(gather_t, n + 1)      # (world * T, N+1) int64 on every rank
         return res
 
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    res = None
-    for _ in range(args.warmup):
-        res = step()
-    fence()
-    kern_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):     # back to back, no host synchronisation inside the timed region
-        res = step()
-    fence()
-    dt = time.perf_counter() - t0
-    for back in range(min(args.steps, 64)):     # HIP events of the timed steps, read afterwards
-        m, f = ctypes.c_double(), ctypes.c_double()
-        if L.tsp2opt_profile_history_ms(local_rank, back, ctypes.byref(m), ctypes.byref(f)) == 0:
-            kern_ms.append((m.value, f.value))
-    if use_dist:
-        tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-        dt = float(tdt.item())
+    res, dt, kernel_ms = h.time_steps(step, args.steps, args.warmup)
 
     if strong:
         whole = res                                  # ShardedResult: whole batch on every rank
@@ -314,15 +497,7 @@ def main():
         if use_dist:        # the gathered copy holds this rank's tours at its own offset
             assert torch.equal(res.all_tours[rank * T:(rank + 1) * T], res.tours), "final gather corrupted the tours"
     sweeps = res.sweeps.to(torch.int64)
-    iters = res.iterations
-    my_pd = torch.tensor([float(sweeps.sum().item()) * pairs, float(local_T), float(iters.sum().item()),
-                          float(iters.max().item()) if local_T else 0.0], dtype=torch.float64, device=dev)
-    if use_dist:
-        mx = my_pd[3:].clone()
-        dist.all_reduce(my_pd, op=dist.ReduceOp.SUM)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        my_pd[3] = mx[0]
-    pd_per_step, tours_total, it_sum, it_max = [float(x) for x in my_pd.tolist()]
+    pd_per_step, tours_total, it_sum, it_max = h.totals(res.sweeps, res.iterations, pairs, local_T)
     value = pd_per_step * args.steps / dt
     status = res.status.cpu().numpy()
     assert (status & (15 | 64)).max(initial=0) == 0, "input rejected"
@@ -339,18 +514,38 @@ def main():
                "max_abs_rel_length_gap": float(rel.abs().max().item()),
                "identical_tours_fraction": float((res.tours == r64.tours).all(dim=1).double().mean().item())}
 
+    # ---- outside the headline's timed region: the other configurations, strong scaling of configs[2] --------
+    extra_configs, strong_obj = [], None
+    if all_configs:
+        for name in ("tsp50", "tsp100", "tsp1000", "tsp10000"):
+            extra_configs.append(run_extra_config(h, name, args.config_steps, 1234, args.max_iterations))
+        for start in ("sampled", "greedy"):
+            extra_configs.append(run_extra_config(h, "tsp500", args.config_steps, 1234, args.max_iterations, start))
+        if use_dist:
+            # BASELINE.json configs[2] as worded: ONE batch of 128 x 16 tours sharded over the ranks
+            sp, st_, _ = make_batch("tsp500", 1234, np.float64)         # the same batch on every rank
+            s_pts, s_tours = torch.from_numpy(sp).to(dev), torch.from_numpy(st_).to(dev)
+            sres, sdt, skern = h.time_steps(lambda: step_strong(s_pts, s_tours), args.steps, 1)
+            b0, b1 = sres.block
+            assert torch.equal(sres.tours[b0:b1], sres.local.tours), "final gather corrupted the tours"
+            spd, stours, sit, _ = h.totals(sres.local.sweeps, sres.local.iterations, pairs, b1 - b0)
+            strong_obj = {"workload": f"TSP-500 uniform, ONE batch of 128 instances x 16 random start tours sharded "
+                                      f"over {world} GPU(s) by sharding.solve_sharded (contiguous instance blocks), "
+                                      "final all_gather of tours / iterations / lengths inside the timed region",
+                          "scaling": "strong", "n_gpus": world, "steps": args.steps, "warmup": 1,
+                          "ms_per_step": sdt / args.steps * 1e3, "value": spd * args.steps / sdt,
+                          "unit": "pair-deltas/s", "tours_per_s": stours * args.steps / sdt,
+                          "tours_per_gpu": b1 - b0, "kernel_ms_rank0": skern}
+
     out = None
     if rank == 0:
-        main_ms = float(np.mean([k[0] for k in kern_ms])) if kern_ms else None
-        forced_ms = float(np.mean([k[1] for k in kern_ms])) if kern_ms else None
         my_pairs = float(sweeps.sum().item()) * pairs
         roof = None
-        if main_ms:
-            kernel_ms = main_ms + (forced_ms or 0.0)
+        if kernel_ms:
             ach = my_pairs * FLOP_PER_PAIR / (kernel_ms * 1e-3) / 1e12
             # counter-derived figures: only for the library they were measured on (else null)
             pmc, why = pmc_for_this_build(args.config, args.mode, args.dtype) if world == 1 else (None, "N = 1 only")
-            exe = busy = bank = evald = traffic = None
+            exe = busy = bank = evald = traffic = cyc64 = None
             if pmc:
                 dv = pmc["derived"]
                 pick = lambda pre: next((v for k, v in dv.items() if k.startswith(pre)), None)
@@ -358,10 +553,20 @@ def main():
                 traffic, sq = pick("hbm_bytes"), pick("sqrt_lanes")
                 exe = exe_flop / (kernel_ms * 1e-3) / 1e12 if exe_flop else None
                 evald = sq / my_pairs if sq and my_pairs else None
+                # SIMD cycles the whole chip spent per 64 pairs the kernel really evaluated (one v_sqrt_f32
+                # wave-instruction = 64 pairs): everything the kernel does -- marking, lists, selection,
+                # reversal, idle issue slots -- is charged to the sweep arithmetic it exists for
+                cyc64 = kernel_ms * 1e-3 * CLOCK_HZ * SIMDS / (sq / 64.0) if sq else None
             roof = {"bound": "valu", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS,
                     "frac_fp32_peak": ach / PEAK_FP32_VALU_TFLOPS, "frac_fp64_peak": ach / PEAK_FP64_VALU_TFLOPS,
                     "executed_tflops": exe, "executed_frac": exe / PEAK_FP32_VALU_TFLOPS if exe else None,
+                    "simd_cycles_per_64_evaluated_pairs": cyc64,
+                    "insn_floor_cycles_per_64_pairs": INSN_FLOOR_CYCLES_PER_64_PAIRS,
+                    "insn_floor_frac": INSN_FLOOR_CYCLES_PER_64_PAIRS / cyc64 if cyc64 else None,
+                    "hardware_fraction": "insn_floor_frac (how close the VALUs run to the measured instruction floor "
+                                         "of the evaluated pairs) and executed_frac (executed FP32 FLOP / vector peak) "
+                                         "are hardware utilisation; frac is reference-equivalent work",
                     "valu_busy": busy, "lds_bank_conflict_rate": bank, "pairs_evaluated_frac": evald,
                     "traffic": traffic, "pmc_source": pmc["_file"] if pmc else why,
                     "kernel": "k_two_opt", "kernel_ms": kernel_ms,
@@ -371,9 +576,10 @@ def main():
                             "the kernel computes in fp32 (exact fp64 only for near-ties) although results are "
                             "bit-exact fp64 (dtype); against the fp64 vector peak 78.6 the same figure is "
                             "frac_fp64_peak and may exceed 1.  The kernel re-evaluates only pairs_evaluated_frac of the "
-                            "pairs per sweep (tile-minimum cache) at one distance per pair: executed_* and valu_busy "
-                            "are what the VALUs really did (rocprofv3 PMC passes of this build; a packed "
-                            "instruction counts once, so executed_tflops is a lower bound).  HBM traffic is O(N) per tour."}
+                            "pairs per sweep (tile-minimum cache, reversals folded onto the shorter side of the cycle) "
+                            "at one distance per pair: executed_*, insn_floor_frac and valu_busy are what the VALUs "
+                            "really did (rocprofv3 PMC passes of this build; a packed instruction counts once, so "
+                            "executed_tflops is a lower bound).  HBM traffic is O(N) per tour."}
         if strong:
             work = (f"TSP-{n} uniform, ONE batch of {inst} instances x {tpi} random start tours sharded over "
                     f"{world} GPU(s) by sharding.solve_sharded (contiguous instance blocks)")
@@ -394,9 +600,13 @@ def main():
         }
         if gap is not None:
             out["fp32_vs_fp64"] = gap
+        if extra_configs:
+            out["configs"] = extra_configs
+        if strong_obj is not None:
+            out["strong"] = strong_obj
         if not args.no_cpu and world == 1:       # the host baseline is timed at N = 1 only
             cb, ref_out, ref_it, cpu_cap = cpu_baseline(args.config, pts, tours, tpi, group,
-                                                        args.max_iterations)
+                                                        args.max_iterations, args.cpu_threads)
             k = len(ref_out)
             chk = res
             if cpu_cap != args.max_iterations:      # untimed GPU run of the sample at the sample's cap

@@ -40,6 +40,23 @@ def _raise_on_status(status: torch.Tensor) -> None:
         raise ValueError(f"tour {int(bad[0])} has an index outside [0, N)")
 
 
+def _check_batch(points: torch.Tensor, tours: torch.Tensor, tours_per_instance: int):
+    """Shapes the kernels index with: tour k reads instance k // tours_per_instance, so the batch must hold
+    exactly I * tours_per_instance tours (the reference raises IndexError at np_points[i] for a missing
+    instance, relocate.py:50; here it is a ValueError before anything is launched)."""
+    if points.dim() != 3 or points.shape[-1] != 2 or tours.dim() != 2:
+        raise ValueError("expected points (I, N, 2) float64 and tours (T, N+1) int64")
+    n, T = points.shape[1], tours.shape[0]
+    if tours.shape[1] != n + 1 or points.dtype != torch.float64 or tours.dtype != torch.int64:
+        raise ValueError("expected points (I, N, 2) float64 and tours (T, N+1) int64")
+    if tours_per_instance < 1 or T != points.shape[0] * tours_per_instance:
+        raise ValueError(f"{T} tours need {T} / tours_per_instance instances, got points for {points.shape[0]} "
+                         f"(tours_per_instance = {tours_per_instance})")
+    if points.device.type != "cuda" or tours.device != points.device:
+        raise ValueError("points and tours must live on the same HIP device")
+    return n, T
+
+
 def ls_step_device(points: torch.Tensor, tours: torch.Tensor, op: int, *, tours_per_instance: int = 1,
                    fixed_i: Optional[torch.Tensor] = None, guide_k: Optional[torch.Tensor] = None,
                    penalty: Optional[torch.Tensor] = None, inplace: bool = False):
@@ -50,11 +67,7 @@ def ls_step_device(points: torch.Tensor, tours: torch.Tensor, op: int, *, tours_
     if tours.dim() == 1:
         tours = tours.unsqueeze(0)
     dev = points.device
-    if dev.type != "cuda" or tours.device != dev:
-        raise ValueError("points and tours must live on the same HIP device")
-    n, T = points.shape[1], tours.shape[0]
-    if tours.shape[1] != n + 1 or points.dtype != torch.float64 or tours.dtype != torch.int64:
-        raise ValueError("expected points (I, N, 2) float64 and tours (T, N+1) int64")
+    n, T = _check_batch(points, tours, int(tours_per_instance))
     points = points.contiguous()
     out = tours.contiguous() if inplace else tours.clone(memory_format=torch.contiguous_format)
     delta = torch.empty(T, dtype=torch.float64, device=dev)
@@ -62,6 +75,12 @@ def ls_step_device(points: torch.Tensor, tours: torch.Tensor, op: int, *, tours_
     fi = None if fixed_i is None else fixed_i.to(device=dev, dtype=torch.int32).contiguous()
     gk = None if guide_k is None else guide_k.to(device=dev, dtype=torch.float64).contiguous()
     pen = None if penalty is None else penalty.to(device=dev, dtype=torch.float64).contiguous()
+    if fi is not None and fi.numel() != T:
+        raise ValueError("fixed_i must hold one row index per tour (T,)")
+    if (gk is None) != (pen is None):
+        raise ValueError("guide_k and penalty go together")
+    if gk is not None and gk.numel() != T:
+        raise ValueError("guide_k must hold one factor per tour (T,)")
     if pen is not None and pen.numel() != T * n * n:
         raise ValueError("penalty must be (T, N, N)")
     rc = _lib.lib().tsp2opt_ls_step(points.data_ptr(), out.data_ptr(), delta.data_ptr(), status.data_ptr(), T, n,
@@ -76,17 +95,15 @@ def ls_step_device(points: torch.Tensor, tours: torch.Tensor, op: int, *, tours_
 
 def local_search_device(points: torch.Tensor, tours: torch.Tensor, *, tours_per_instance: int = 1,
                         max_rounds: int = 1 << 30, inplace: bool = False):
-    """``local_search`` (search/local_search.py:125-134) for every tour.  Returns ``(tours, rounds int32)``."""
+    """``local_search`` (search/local_search.py:125-134) for every tour.  Returns ``(tours, rounds int32)``.
+    A tour whose search was stopped by ``max_rounds`` (``TSP2OPT_ST_CAPPED``) has ``rounds == max_rounds``:
+    callers that pass a cap check that; the default cap is never reached by a terminating search."""
     if points.dim() == 2:
         points = points.unsqueeze(0)
     if tours.dim() == 1:
         tours = tours.unsqueeze(0)
     dev = points.device
-    if dev.type != "cuda" or tours.device != dev:
-        raise ValueError("points and tours must live on the same HIP device")
-    n, T = points.shape[1], tours.shape[0]
-    if tours.shape[1] != n + 1 or points.dtype != torch.float64 or tours.dtype != torch.int64:
-        raise ValueError("expected points (I, N, 2) float64 and tours (T, N+1) int64")
+    n, T = _check_batch(points, tours, int(tours_per_instance))
     points = points.contiguous()
     out = tours.contiguous() if inplace else tours.clone(memory_format=torch.contiguous_format)
     rounds = torch.empty(T, dtype=torch.int32, device=dev)
@@ -111,6 +128,8 @@ def tsp_relocate(np_points, tours, adj_mat=None, device="cpu", **kwargs):
     if p.ndim == 2:
         p = p[None]
     count = t.shape[0] if adj_mat is None else (1 if np.ndim(adj_mat) == 2 else np.shape(adj_mat)[0])
+    if p.shape[0] < count or t.shape[0] < count:     # the reference: IndexError at np_points[i] / tours[i]
+        raise ValueError(f"{count} tours need {count} coordinate sets, got {p.shape[0]} (and {t.shape[0]} tours)")
     out, _ = ls_step_device(_to_dev(p[:count], dev, torch.float64), _to_dev(t[:count], dev, torch.int64), 1)
     return [r.tolist() for r in out.cpu().numpy()]
 

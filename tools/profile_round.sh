@@ -12,7 +12,7 @@ for st in $STAGES; do
   echo "== stage $st"
   case $st in
   bench) timeout -k 10 200 python bench.py > $O/${TAG}_bench_tsp500.json 2> $O/${TAG}_bench_tsp500.err || exit 1 ;;
-  kt) timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -- python bench.py --steps 4 --warmup 1 --no-cpu > $O/${TAG}_kt.log 2>&1 || exit 1
+  kt) timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -- python bench.py --steps 4 --warmup 1 --no-cpu --no-configs > $O/${TAG}_kt.log 2>&1 || exit 1
       cp $(find $O/${TAG}_kt -name '*kernel_stats.csv' | head -1) $O/${TAG}_kernel_stats.csv ;;
   pmc) bash tools/pmc_passes.sh || exit 1
        python tools/summarize_pmc.py > $O/${TAG}_tsp500_pmc_summary.json || exit 1 ;;
@@ -56,7 +56,7 @@ for st in $STAGES; do
       TSP2OPT_LIB=$PWD/ml4tspbench_amd/libtsp2opt_hip_fine.so timeout -k 10 120 python tools/phase_breakdown.py $c > $O/${TAG}_phase_$c.txt 2>&1 || exit 1
     done
     TSP2OPT_LIB=$PWD/ml4tspbench_amd/libtsp2opt_hip_fine.so timeout -k 10 200 python tools/phase_breakdown.py tsp10000 f64 1000 > $O/${TAG}_phase_tsp10000.txt 2>&1 || exit 1 ;;
-  strong) timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu --scaling strong > $O/${TAG}_bench_strong1.json 2> $O/${TAG}_bench_strong1.err || exit 1 ;;
+  strong) timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu --no-configs --scaling strong > $O/${TAG}_bench_strong1.json 2> $O/${TAG}_bench_strong1.err || exit 1 ;;
   dist) timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu > $O/${TAG}_bench_dist1.json 2> $O/${TAG}_bench_dist1.err || exit 1 ;;
   esac
 done

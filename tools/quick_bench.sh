@@ -2,7 +2,7 @@
 # tools/quick_bench.sh -- kernel times of every BASELINE config + the small-batch TSP-500 case (no CPU leg)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 pr() { python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$1', 'ms_per_step=%.3f kernel_ms=%.3f frac=%.3f value=%.3e' % (d['ms_per_step'], r['kernel_ms'], r['frac'], d['value']))"; }
-timeout -k 10 120 python bench.py --no-cpu --steps 5 | pr tsp500x2048 || exit 1
+timeout -k 10 120 python bench.py --no-cpu --no-configs --steps 5 | pr tsp500x2048 || exit 1
 timeout -k 10 120 python bench.py --no-cpu --instances 16 | pr tsp500x256 || exit 1
 timeout -k 10 120 python bench.py --no-cpu --instances 512 --steps 3 | pr tsp500x8192 || exit 1
 timeout -k 10 120 python bench.py --no-cpu --config tsp50 | pr tsp50 || exit 1

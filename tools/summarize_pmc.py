@@ -17,7 +17,7 @@ simd_cycles = out.get("GRBM_GUI_ACTIVE", 0) / 8 * 1024      # GRBM summed over 8
 lib = os.path.join("ml4tspbench_amd", "libtsp2opt_hip.so")
 d = {
   "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
-  "command": "python bench.py --steps 1 --warmup 0 --no-cpu (one rocprofv3 --pmc run per pass, tools/pmc_passes.sh)",
+  "command": "python bench.py --steps 1 --warmup 0 --no-cpu --no-configs (one rocprofv3 --pmc run per pass, tools/pmc_passes.sh)",
   "k_two_opt_launches_per_pass": nl,
   "counters": out,
   "derived": {
