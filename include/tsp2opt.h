@@ -110,6 +110,9 @@ int64_t tsp2opt_workspace_bytes(int64_t num_tours, int32_t n, int32_t group_size
  *     inside a graph capture.
  *   - Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two streams,
  *     two threads) race.  Issue them on one stream, or order them with events.
+ *   - Under stream capture the call records only memsets and kernel launches (the per-device event that
+ *     orders multi-workgroup launches of different streams is neither waited on nor recorded while the
+ *     stream captures): replays of the graph must not overlap other multi-workgroup calls on that GPU.
  */
 int tsp2opt_solve_noalloc(const void* points, int64_t* tours, int32_t* iters_out, int32_t* sweeps_out,
                           double* lengths_out, int32_t* status_out, int64_t num_tours, int32_t n,

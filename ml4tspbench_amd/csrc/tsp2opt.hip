@@ -156,10 +156,24 @@ int scratch_setup(int device, void** out)
     return 0;
 }
 
+// A stream under graph capture is left out of the chain: an event recorded inside a capture becomes a node
+// of that graph, and the next uncaptured launch that waited on it would fail.  The launches of one captured
+// graph are ordered by the graph itself; replays of such a graph that run at the same time as other cluster
+// launches on the same GPU are the caller's to order (include/tsp2opt.h, tsp2opt_solve_noalloc).
+bool stream_is_capturing(hipStream_t stream)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+
+// chain_begin / chain_end: the CALLER holds g_chain[device].mu from before chain_begin until after chain_end
+// (launch_fw, launch_cluster), so wait + launch + record of one call are atomic with respect to other threads.
 int chain_begin(int device, hipStream_t stream)
 {
     if (device < 0 || device >= kMaxDev) return 0;
     ClusterChain& c = g_chain[device];
+    if (stream_is_capturing(stream)) return 0;
     if (!c.ev) HIP_TRY(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
     if (c.recorded) HIP_TRY(hipStreamWaitEvent(stream, c.ev, 0));
     return 0;
@@ -169,6 +183,7 @@ int chain_end(int device, hipStream_t stream)
 {
     if (device < 0 || device >= kMaxDev) return 0;
     ClusterChain& c = g_chain[device];
+    if (stream_is_capturing(stream)) return 0;
     HIP_TRY(hipEventRecord(c.ev, stream));
     c.recorded = true;
     return 0;

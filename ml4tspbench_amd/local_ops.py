@@ -120,7 +120,6 @@ def tsp_relocate(np_points, tours, adj_mat=None, device="cpu", **kwargs):
     """Drop-in for ``search/relocate.py:40-61``: the best relocate move of every tour, applied once.
     Like the reference, ``adj_mat`` only supplies the number of tours (its leading dimension) and tour
     ``i`` uses ``np_points[i]``; returns a list of tours (lists of N+1 ints)."""
-    dev = _resolve_device(device)
     t = np.array(tours)
     if t.ndim == 1:
         t = t[None]
@@ -130,6 +129,7 @@ def tsp_relocate(np_points, tours, adj_mat=None, device="cpu", **kwargs):
     count = t.shape[0] if adj_mat is None else (1 if np.ndim(adj_mat) == 2 else np.shape(adj_mat)[0])
     if p.shape[0] < count or t.shape[0] < count:     # the reference: IndexError at np_points[i] / tours[i]
         raise ValueError(f"{count} tours need {count} coordinate sets, got {p.shape[0]} (and {t.shape[0]} tours)")
+    dev = _resolve_device(device)
     out, _ = ls_step_device(_to_dev(p[:count], dev, torch.float64), _to_dev(t[:count], dev, torch.int64), 1)
     return [r.tolist() for r in out.cpu().numpy()]
 

@@ -27,7 +27,7 @@ def _oracle_solver(points, tours, *, tours_per_instance, group_size, max_iterati
                            lengths=torch.from_numpy(lengths))
 
 
-def _worker(rank, world, port, inst, tpi, group, n, ret):
+def _worker(rank, world, port, inst, tpi, group, n, form, ret):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -39,9 +39,20 @@ def _worker(rank, world, port, inst, tpi, group, n, ret):
         tours = np.zeros((inst * tpi, n + 1), dtype=np.int64)
         for k in range(inst * tpi):
             tours[k, 1:n] = rng.permutation(np.arange(1, n))
-        t, it, ln = solve_sharded(torch.from_numpy(pts), torch.from_numpy(tours),
-                                  tours_per_instance=tpi, group_size=group, max_iterations=5000,
-                                  solver=_oracle_solver)
+        if form == "local":
+            # every rank passes ONLY its own block (uneven on purpose: rank 0 holds one instance, or none)
+            cut = min(1, inst - 1)
+            a, b = (0, cut) if rank == 0 else (cut, inst)
+            t, it, ln = solve_sharded(torch.from_numpy(pts[a:b]), torch.from_numpy(tours[a * tpi:b * tpi]),
+                                      tours_per_instance=tpi, group_size=group, max_iterations=5000,
+                                      solver=_oracle_solver, local_inputs=True)
+        else:
+            res = solve_sharded(torch.from_numpy(pts), torch.from_numpy(tours),
+                                tours_per_instance=tpi, group_size=group, max_iterations=5000,
+                                solver=_oracle_solver, balance=form, want_result=True)
+            t, it, ln = res.tours, res.iterations, res.lengths
+            # the rank's own rows sit where tour_index says
+            assert torch.equal(t[res.tour_index], res.local.tours)
         ref = _oracle_solver(torch.from_numpy(pts), torch.from_numpy(tours), tours_per_instance=tpi,
                              group_size=group, max_iterations=5000)
         ok = (torch.equal(t, ref.tours) and torch.equal(it, ref.iterations)
@@ -57,12 +68,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("inst,tpi,group", [(5, 4, 1), (5, 4, 4), (4, 2, 2), (1, 3, 1)])
-def test_sharded_solve_equals_unsharded_world2(inst, tpi, group):
+@pytest.mark.parametrize("inst,tpi,group,form", [
+    (5, 4, 1, "contiguous"), (5, 4, 4, "contiguous"), (4, 2, 2, "contiguous"), (1, 3, 1, "contiguous"),
+    (5, 4, 4, "interleaved"), (7, 2, 1, "proxy"), (1, 3, 3, "proxy"),
+    (5, 4, 2, "local"), (1, 3, 1, "local")])
+def test_sharded_solve_equals_unsharded_world2(inst, tpi, group, form):
+    """form: the replicated input form with that `balance`, or "local" = every rank passes only its block."""
     from oracle import two_opt_oracle
     two_opt_oracle.build()
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), inst, tpi, group, 24, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), inst, tpi, group, 24, form, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}

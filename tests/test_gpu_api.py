@@ -173,3 +173,63 @@ def test_anytime_checkpoints_follow_the_capped_trajectory(oracle):
     L = timed.lengths.cpu().numpy()
     assert (np.diff(L, axis=1) <= 1e-12).all() and (np.diff(timed.times.numpy()) > 0).all()
     assert timed.converged.all() and np.array_equal(timed.tours.cpu().numpy(), full)
+
+
+def test_zero_tour_batches_are_accepted():
+    """A rank of a sharded solve may own no instance (1 instance on 2 GPUs): two_opt_device and the C entry
+    point take an empty batch and return empty results without launching anything."""
+    import ml4tspbench_amd as amd
+    from ml4tspbench_amd import _lib
+    dev = torch.device("cuda", 0)
+    pts = torch.zeros((0, 40, 2), dtype=torch.float64, device=dev)
+    tours = torch.zeros((0, 41), dtype=torch.int64, device=dev)
+    for group in (1, 4):
+        res = amd.two_opt_device(pts, tours, tours_per_instance=4, group_size=group)
+        torch.cuda.synchronize()
+        assert res.tours.shape == (0, 41) and res.iterations.shape == (0,) and res.lengths.shape == (0,)
+    L = _lib.lib()
+    rc = L.tsp2opt_solve(None, None, None, None, None, None, 0, 40, 1, 1, 5000, 0.0, 1, 0, None, 0, None)
+    assert rc == 0, L.tsp2opt_last_error()
+    assert L.tsp2opt_solve_noalloc(None, None, None, None, None, None, 0, 40, 1, 1, 5000, 0.0, 1, 0, None) == 0
+    torch.cuda.synchronize()
+    ev = amd.evaluate_tours(pts, tours, tours_per_instance=1)
+    assert ev.lengths.shape == (0,)
+
+
+def test_solve_sharded_world1_nccl_with_the_real_solver(oracle):
+    """sharding.solve_sharded with two_opt_device under an initialised nccl (RCCL) group of one rank: the code
+    path of the N-GPU launch (assignment, solve, final gather) with the real kernel, every input form."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from ml4tspbench_amd.sharding import solve_sharded
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(31)
+        inst, tpi, n = 6, 4, 60
+        pts = rng.random((inst, n, 2))
+        tours = np.zeros((inst * tpi, n + 1), dtype=np.int64)
+        for k in range(inst * tpi):
+            tours[k, 1:n] = rng.permutation(np.arange(1, n))
+        d_p, d_t = torch.from_numpy(pts).to(dev), torch.from_numpy(tours).to(dev)
+        for group in (1, 4):
+            ref, ref_it, _ = oracle.solve(pts, tours, tours_per_instance=tpi, group_size=group)
+            for kw in ({}, {"balance": "interleaved"}, {"balance": "proxy"}, {"local_inputs": True}):
+                r = solve_sharded(d_p, d_t, tours_per_instance=tpi, group_size=group, want_result=True, **kw)
+                assert np.array_equal(r.tours.cpu().numpy(), ref), (group, kw)
+                assert np.array_equal(r.iterations.cpu().numpy(), ref_it), (group, kw)
+                assert torch.equal(r.tours[r.tour_index], r.local.tours)
+        # an all_reduce on the same communicator still works afterwards (the solve left the stream usable)
+        x = torch.ones(4, device=dev)
+        dist.all_reduce(x)
+        assert float(x.sum().item()) == 4.0
+        e = solve_sharded(d_p[:0], d_t[:0], tours_per_instance=tpi, local_inputs=True)
+        assert e[0].shape == (0, n + 1)
+    finally:
+        dist.destroy_process_group()

@@ -89,6 +89,45 @@ def test_partition_is_contiguous_and_balanced():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_assign_units_covers_every_unit_once_and_balances():
+    from ml4tspbench_amd.sharding import assign_units, partition
+    rng = np.random.default_rng(3)
+    for units in (0, 1, 7, 8, 9, 128):
+        for world in (1, 2, 3, 8):
+            cost = rng.random(units) ** 3 * 100
+            for balance in ("contiguous", "interleaved", "proxy"):
+                got = assign_units(units, world, balance, cost.tolist())
+                assert len(got) == world and sorted(u for g in got for u in g) == list(range(units))
+                assert all(g == sorted(g) for g in got)
+                sizes = [len(g) for g in got]
+                assert max(sizes) - min(sizes) <= 1
+            assert assign_units(units, world) == [list(range(a, b)) for a, b in partition(units, world)]
+    # the proxy assignment evens out a batch whose cost grows along the batch; contiguous blocks do not
+    cost = np.arange(64, dtype=float) ** 2
+    load = lambda got: max(sum(cost[u] for u in g) for g in got) / (cost.sum() / len(got))
+    assert load(assign_units(64, 8, "proxy", cost.tolist())) < 1.05 < load(assign_units(64, 8, "contiguous"))
+    assert load(assign_units(64, 8, "interleaved")) < 1.25
+    with pytest.raises(ValueError):
+        assign_units(4, 2, "proxy")
+
+
+def test_ls_ops_reject_inconsistent_batches_before_any_launch():
+    """T must equal I * tours_per_instance, fixed_i / guide_k one entry per tour -- checked on
+    the host (CPU tensors get as far as the device check, which comes last)."""
+    import torch
+    from ml4tspbench_amd import local_ops
+    pts = torch.zeros((1, 6, 2), dtype=torch.float64)
+    tours = torch.zeros((3, 7), dtype=torch.int64)
+    with pytest.raises(ValueError, match="tours need"):
+        local_ops.ls_step_device(pts, tours, 1)                       # 3 tours, one instance, tpi = 1
+    with pytest.raises(ValueError, match="tours need"):
+        local_ops.local_search_device(pts, tours, tours_per_instance=2)
+    with pytest.raises(ValueError, match="HIP device"):
+        local_ops.ls_step_device(pts, tours, 1, tours_per_instance=3)  # consistent: only the device is wrong
+    with pytest.raises(ValueError, match="coordinate sets"):
+        local_ops.tsp_relocate(np.zeros((6, 2)), np.zeros((3, 7), dtype=np.int64))   # one (N, 2) set, 3 tours
+
+
 def test_txt_format_round_trip(tmp_path):
     """Dataset text format of the reference (generate.py:147-153, solvers/solver.py:51-78,115-138)."""
     from ml4tspbench_amd.io import read_txt, write_txt

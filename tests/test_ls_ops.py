@@ -145,6 +145,35 @@ def test_gpu_long_relocate_shift_both_directions(lso):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,rounds", [(2000, 3), (12000, 1)])
+def test_gpu_large_n_scan_paths_match_oracle(lso, n, rounds):
+    """The two scan paths that only large tours reach (csrc/ls_ops.hip ls_best): rows per lane once the flat
+    candidate tables no longer fit the LDS (n above about 1555) and coordinates read from global memory
+    (n above about 9100).  Both operators for one step, and a capped local_search."""
+    import ml4tspbench_amd as amd
+    rng = np.random.default_rng(n)
+    inst = 2
+    pts = rng.random((inst, n, 2))
+    tours = np.zeros((inst, n + 1), dtype=np.int64)
+    for k in range(inst):
+        # a short random walk away from a space-filling order keeps the oracle's O(n^2) loops to a few rounds
+        order = np.lexsort((pts[k, :, 1], np.floor(pts[k, :, 0] * 24)))
+        order = order[order != 0]
+        sw = rng.integers(0, n - 1, size=(40, 2))
+        for a, b in sw:
+            order[[a, b]] = order[[b, a]]
+        tours[k, 1:n] = order
+    d_p, d_t = _dev(pts, torch.float64), _dev(tours, torch.int64)
+    for op in (0, 1):
+        ref, d = lso.step(pts, tours, op)
+        out, e = amd.ls_step_device(d_p, d_t, op)
+        assert np.array_equal(out.cpu().numpy(), ref) and np.array_equal(e.cpu().numpy(), d), (n, op)
+    ref, ref_rounds = lso.local_search(pts, tours, max_rounds=rounds)
+    out, got_rounds = amd.local_search_device(d_p, d_t, max_rounds=rounds)
+    assert np.array_equal(out.cpu().numpy(), ref) and np.array_equal(got_rounds.cpu().numpy(), ref_rounds)
+
+
+@pytest.mark.gpu
 def test_gpu_guided_local_search_matches_reference():
     import ml4tspbench_amd as amd
     for name, z in _load("ls_gls_*.npz"):

@@ -88,18 +88,56 @@ def test_noalloc_rejects_oversized_batches_and_allocates_nothing():
     d_p = torch.from_numpy(pts).to(dev)
     d_t = torch.from_numpy(tours).to(dev)
     iters = torch.empty(64, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    outs = [torch.empty_like(d_t) for _ in range(5)]        # every output exists BEFORE free memory is read:
+    stream = torch.cuda.current_stream(dev).cuda_stream     # inside the loop torch allocates nothing either
 
-    def once():
-        out = d_t.clone()
+    def once(out):
+        out.copy_(d_t)
         rc = L.tsp2opt_solve_noalloc(d_p.data_ptr(), out.data_ptr(), iters.data_ptr(), None, None, None, 64, 80,
                                      2, 1, 5000, 0.0, 1, 0, stream)
         assert rc == 0
         torch.cuda.synchronize()
-        return out
 
-    once()
+    once(outs[0])
     free0 = torch.cuda.mem_get_info(dev)[0]
-    outs = [once() for _ in range(4)]
-    assert torch.cuda.mem_get_info(dev)[0] >= free0
+    reserved0 = torch.cuda.memory_reserved(dev)
+    for o in outs[1:]:
+        once(o)
+    assert torch.cuda.mem_get_info(dev)[0] == free0 and torch.cuda.memory_reserved(dev) == reserved0
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+@pytest.mark.parametrize("n,inst,cap", [(100, 48, 5000), (1000, 3, 200)])
+def test_noalloc_under_graph_capture_replays_like_solve(n, inst, cap):
+    """include/tsp2opt.h names graph capture as a caller of tsp2opt_solve_noalloc: capture one call (n = 100:
+    one workgroup per tour; n = 1000: the full-window cluster, whose launch chain event must stay out of the
+    capture), replay it twice on fresh inputs and compare with tsp2opt_solve; an uncaptured cluster call
+    afterwards must still work."""
+    from ml4tspbench_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    assert L.tsp2opt_init(0) == 0, L.tsp2opt_last_error()
+    rng = np.random.default_rng(77 + n)
+    pts, tours = _batch(rng, inst, 1, n, np.float64)
+    ref = _call(L, False, pts, tours, 1, 1, cap, dev)
+    d_p = torch.from_numpy(pts).to(dev)
+    d_in = torch.from_numpy(tours).to(dev)
+    out = d_in.clone()
+    iters = torch.zeros(inst, dtype=torch.int32, device=dev)
+    lengths = torch.zeros(inst, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out.copy_(d_in)
+        rc = L.tsp2opt_solve_noalloc(d_p.data_ptr(), out.data_ptr(), iters.data_ptr(), None, lengths.data_ptr(), None,
+                                     inst, n, 1, 1, cap, 0.0, 1, 0, torch.cuda.current_stream(dev).cuda_stream)
+    assert rc == 0, L.tsp2opt_last_error()
+    for _ in range(2):
+        out.zero_()
+        iters.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), ref[0]) and np.array_equal(iters.cpu().numpy(), ref[1])
+        assert np.array_equal(lengths.cpu().numpy(), ref[4])
+    again = _call(L, True, pts, tours, 1, 1, cap, dev)      # uncaptured call after the capture
+    assert np.array_equal(again[0], ref[0])
