@@ -355,7 +355,7 @@ __device__ __forceinline__ double exact_delta_c(const CView<T>& v, int i, int j)
     View<T> w;
     w.tour = v.tour;
     w.X = v.X;
-    return exact_delta(w, i, j);
+    return exact_delta(w, 1 << 30, i, j);       // identity frame: positions are used as they are
 }
 
 // exact value of pair `pr` (0..31) of macro step `m` of local unit `u`; false for padding units

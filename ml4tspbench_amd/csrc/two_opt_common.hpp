@@ -161,16 +161,34 @@ struct View {
     uint16_t* list;        // ids of the tiles the last reversal touched
     unsigned* Mu;          // per unit (lane): order-preserving key of the minimum over its tiles, or null
     const T* X;            // exact coordinates, node order (LDS copy or global)
+    // Frame of the LDS copy against the reference's array R[0..n] (two_opt.py:12 `cuda_tour`):
+    // R[k] = tour[(fo + fs * k) mod n], fs = +1 or -1.  The cycle is what the filter works on; a reversal of
+    // R[i+1..j] that covers more than half of it is applied to the COMPLEMENT instead (same cycle, opposite
+    // orientation: fs flips, fo moves), which touches fewer positions -- see resolve_move.  Wave-uniform.
+    int fo = 0, fs = 1;
 };
+
+// p in (-n, 2n) -> [0, n)
+__device__ __forceinline__ int wrapn(int p, int n)
+{
+    p += p < 0 ? n : 0;
+    p -= p >= n ? n : 0;
+    return p;
+}
+
+// LDS position of reference position k, 0 <= k <= n
+template <typename T>
+__device__ __forceinline__ int ipos(const View<T>& v, int n, int k) { return wrapn(v.fo + v.fs * k, n); }
 
 template <int Q>
 __device__ __forceinline__ int slot(int w) { return (w & 7) * Q + (w >> 3); }
 
 // exact delta of position pair (i, j), i + 2 <= j <= n-1, in the reference's operation order
 template <typename T>
-__device__ __forceinline__ double exact_delta(const View<T>& v, int i, int j)
+__device__ __forceinline__ double exact_delta(const View<T>& v, int n, int i, int j)
 {
-    const int ti = v.tour[i], ti1 = v.tour[i + 1], tj = v.tour[j], tj1 = v.tour[j + 1];
+    const int ti = v.tour[ipos(v, n, i)], ti1 = v.tour[ipos(v, n, i + 1)];
+    const int tj = v.tour[ipos(v, n, j)], tj1 = v.tour[ipos(v, n, j + 1)];
     const T xi = v.X[2 * ti], yi = v.X[2 * ti + 1];
     const T xi1 = v.X[2 * ti1], yi1 = v.X[2 * ti1 + 1];
     const T xj = v.X[2 * tj], yj = v.X[2 * tj + 1];
@@ -192,14 +210,14 @@ __device__ void exact_sweep(const View<T>& v, int n, int tid, int nt, double& e,
     e = 0.0;
     idx = kNoMove;
     for (int i = tid; i + 2 <= n - 1; i += nt) {
-        const int ti = v.tour[i], ti1 = v.tour[i + 1];
+        const int ti = v.tour[ipos(v, n, i)], ti1 = v.tour[ipos(v, n, i + 1)];
         const T xi = v.X[2 * ti], yi = v.X[2 * ti + 1];
         const T xi1 = v.X[2 * ti1], yi1 = v.X[2 * ti1 + 1];
         const T a_ii1 = dist_exact(xi, yi, xi1, yi1);
-        int tj = v.tour[i + 2];
+        int tj = v.tour[ipos(v, n, i + 2)];
         T xj = v.X[2 * tj], yj = v.X[2 * tj + 1];
         for (int j = i + 2; j <= n - 1; ++j) {
-            const int tj1 = v.tour[j + 1];
+            const int tj1 = v.tour[ipos(v, n, j + 1)];
             const T xj1 = v.X[2 * tj1], yj1 = v.X[2 * tj1 + 1];
             const T a_ij = dist_exact(xi, yi, xj, yj);
             const T a_i1j1 = dist_exact(xi1, yi1, xj1, yj1);

@@ -245,14 +245,16 @@ __device__ __forceinline__ void filter_sweep_cached(const View<T>& v, const Geo&
     v.Mu[tid] = fkey(um);
 }
 
-// phase A, second half: mark the tiles reversal `mv` touches (coordinates i+1..j, edges i..j, any
-// cyclic copy), reset the unit minimum to its untouched tiles, queue the touched tile ids
+// phase A, second half: mark the tiles the reversal of LDS positions lo0 .. lo0 + len - 1 (mod n) touches
+// (those coordinates and the edges lo0 - 1 .. lo0 + len - 1, in every cyclic copy of the window), reset the
+// unit minimum to its untouched tiles, queue the touched tile ids
 template <bool CL, typename T>
-__device__ __forceinline__ void mark_touched(const View<T>& v, const Geo& g, int tid, unsigned mv)
+__device__ __forceinline__ void mark_touched(const View<T>& v, const Geo& g, int tid, int lo0, int len)
 {
     const Unit un = lane_unit<CL>(g, tid);
     const int MS2 = g.MS >> 1;
-    const int i = (int)(mv >> 16), j = (int)(mv & 0xffffu);
+    int i = lo0 - 1, j = lo0 + len - 1;                 // window positions [i, j] (+ k n) read changed values
+    if (j >= g.n) { i -= g.n; j -= g.n; }               // (uniform) the earliest copy that reaches the window
     unsigned mask = 0u;                                 // touched tiles of the lane's unit (MS2 <= 32)
     if (un.gp >= 0) {
         for (int lo = i, hi = j; lo < g.W; lo += g.n, hi += g.n) {
@@ -296,6 +298,20 @@ __device__ __forceinline__ void mark_touched(const View<T>& v, const Geo& g, int
     }
 }
 
+// Filter value of the reference pair (0, n-1): cyclically adjacent edges, on no walked diagonal.  Its operands
+// are R[0], R[1], R[n-1] and the edges between them, wherever the frame has put them.
+template <int Q, typename T>
+__device__ __forceinline__ float special_pair_filter(const View<T>& v, int n)
+{
+    const int p0 = v.fo, p1 = wrapn(v.fo + v.fs, n), pm = wrapn(v.fo - v.fs, n);
+    const int e0 = v.fs > 0 ? p0 : p1, em = v.fs > 0 ? pm : p0;         // LDS edges (R0,R1) and (R[n-1],R0)
+    const int s0 = slot<Q>(p0), s1 = slot<Q>(p1), sm = slot<Q>(pm);
+    const float x0 = v.Xq[s0].x, y0 = v.Yq[s0].x;
+    const float d0 = dist32(x0, y0, v.Xq[sm].x, v.Yq[sm].x);
+    const float d1 = dist32(v.Xq[s1].x, v.Yq[s1].x, x0, y0);
+    return ((d0 + d1) - v.Eq[slot<Q>(em)].x) - v.Eq[slot<Q>(e0)].x;
+}
+
 // phase B: bring Mc / Mu up to date after reversal `last` (kFullSweep: everything)
 template <int Q, bool CL, typename T>
 __device__ __forceinline__ void refresh_cached(const View<T>& v, const Geo& g, int tid, unsigned last, Prof& pf)
@@ -325,12 +341,10 @@ __device__ __forceinline__ void refresh_cached(const View<T>& v, const Geo& g, i
     __builtin_amdgcn_s_setprio(3);
     if (tid == 0) {     // the pair (0, n-1): cyclically adjacent, not on any walked diagonal
         const int n = g.n;
-        if (last == kFullSweep || (last >> 16) == 0u || (last & 0xffffu) == (unsigned)(n - 1)) {
-            const int s0 = slot<Q>(0), s1 = slot<Q>(1), sn1 = slot<Q>(n - 1), sn = slot<Q>(n);
-            const float d0 = dist32(v.Xq[s0].x, v.Yq[s0].x, v.Xq[sn1].x, v.Yq[sn1].x);
-            const float d1 = dist32(v.Xq[s1].x, v.Yq[s1].x, v.Xq[sn].x, v.Yq[sn].x);
-            ctl->spd = ((d0 + d1) - v.Eq[sn1].x) - v.Eq[s0].x;
-        }
+        // (its operands R[1], R[n-1] and the two edges change only when the reversal starts at reference
+        //  position 1 or ends at n-1, whatever the frame)
+        if (last == kFullSweep || (last >> 16) == 0u || (last & 0xffffu) == (unsigned)(n - 1))
+            ctl->spd = special_pair_filter<Q>(v, n);
     }
 }
 
@@ -349,6 +363,18 @@ __device__ __forceinline__ void tile_pair(const Geo& g, unsigned id, int pr, int
     cw = rw + 2 + 8 * (g.wc + g.CS * (int)(id & 255u)) + (pr & 7);
 }
 
+// Reference index (two_opt.py:37-38: i, j of the flat argmin) of the pair of LDS edges r and c (edge q joins
+// LDS positions q and q + 1): LDS position p is reference position fs * (p - fo) mod n, and with fs = -1 the
+// edge's first reference position is that of its SECOND LDS position.  Returns packed (i << 16 | j), i < j.
+template <typename T>
+__device__ __forceinline__ unsigned pair_index(const View<T>& v, int n, int r, int c)
+{
+    const int er = v.fs > 0 ? wrapn(r - v.fo, n) : wrapn(v.fo - 1 - r, n);
+    const int ec = v.fs > 0 ? wrapn(c - v.fo, n) : wrapn(v.fo - 1 - c, n);
+    const int i = er < ec ? er : ec, j = er < ec ? ec : er;
+    return ((unsigned)i << 16) | (unsigned)j;
+}
+
 // exact value of pair `pr` of tile `id`; returns packed index
 template <typename T>
 __device__ __forceinline__ void eval_chunk_pair(const View<T>& v, const Geo& g, unsigned id, int pr,
@@ -356,10 +382,8 @@ __device__ __forceinline__ void eval_chunk_pair(const View<T>& v, const Geo& g, 
 {
     int rw, cw;
     tile_pair(g, id, pr, rw, cw);
-    const int r = wrap3(rw, g.n), c = wrap3(cw, g.n);
-    const int i = r < c ? r : c, j = r < c ? c : r;
-    e = exact_delta(v, i, j);
-    idx = ((unsigned)i << 16) | (unsigned)j;
+    idx = pair_index(v, g.n, wrap3(rw, g.n), wrap3(cw, g.n));
+    e = exact_delta(v, g.n, (int)(idx >> 16), (int)(idx & 0xffffu));
 }
 
 // fp32 (filter) value of pair `pr` of tile `id`, recomputed from the LDS window exactly as the
@@ -374,9 +398,7 @@ __device__ __forceinline__ void filter_chunk_pair(const View<T>& v, const Geo& g
     const float d0 = dist32(v.Xq[sr].x, v.Yq[sr].x, v.Xq[sc].x, v.Yq[sc].x);
     const float d1 = dist32(v.Xq[sr1].x, v.Yq[sr1].x, v.Xq[sc1].x, v.Yq[sc1].x);
     d = ((d0 + d1) - v.Eq[sc].x) - v.Eq[sr].x;
-    const int r = wrap3(rw, g.n), c = wrap3(cw, g.n);
-    const int i = r < c ? r : c, j = r < c ? c : r;
-    idx = ((unsigned)i << 16) | (unsigned)j;
+    idx = pair_index(v, g.n, wrap3(rw, g.n), wrap3(cw, g.n));
 }
 
 // filter_chunk_pair with every LDS read issued before the first use (one round trip instead of six)
@@ -394,9 +416,7 @@ __device__ __forceinline__ void filter_chunk_pair_b(const View<T>& v, const Geo&
     const float d0 = dist32(xr, yr, xc, yc);
     const float d1 = dist32(xr1, yr1, xc1, yc1);
     d = ((d0 + d1) - ec) - er;
-    const int r = wrap3(rw, g.n), c = wrap3(cw, g.n);
-    const int i = r < c ? r : c, j = r < c ? c : r;
-    idx = ((unsigned)i << 16) | (unsigned)j;
+    idx = pair_index(v, g.n, wrap3(rw, g.n), wrap3(cw, g.n));
 }
 
 // One full argmin (the reference's per-tour torch.min / torch.argmin, two_opt.py:35-38) for geometries
@@ -484,12 +504,8 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
                 }
                 if (tid == 0) {     // the pair (0, n-1): cyclically adjacent, not on any walked diagonal
                     const int n = g.n;
-                    if (last == kFullSweep || (last >> 16) == 0u || (last & 0xffffu) == (unsigned)(n - 1)) {
-                        const int s0 = slot<Q>(0), s1 = slot<Q>(1), sn1 = slot<Q>(n - 1), sn = slot<Q>(n);
-                        const float d0 = dist32(v.Xq[s0].x, v.Yq[s0].x, v.Xq[sn1].x, v.Yq[sn1].x);
-                        const float d1 = dist32(v.Xq[s1].x, v.Yq[s1].x, v.Xq[sn].x, v.Yq[sn].x);
-                        ctl->spd = ((d0 + d1) - v.Eq[sn1].x) - v.Eq[s0].x;
-                    }
+                    if (last == kFullSweep || (last >> 16) == 0u || (last & 0xffffu) == (unsigned)(n - 1))
+                        ctl->spd = special_pair_filter<Q>(v, n);
                     const float d = ctl->spd;
                     const unsigned di = (unsigned)(n - 1);
                     if (d <= thr) {
@@ -565,7 +581,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
                 if (better(d, di, e, idx)) { e = d; idx = di; }
             }
             if (tid == 0) {
-                const double d = exact_delta(v, 0, g.n - 1);
+                const double d = exact_delta(v, g.n, 0, g.n - 1);
                 if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
             }
             wave_best(e, idx);
@@ -721,7 +737,7 @@ __device__ void select_cached(const View<T>& v, const Geo& g, int tid, bool need
             if (nct >= 0) {
                 // the pair (0, n-1): its filter value gates the exact evaluation exactly like a tile's minimum
                 if (spd <= thr) {                       // (uniform)
-                    const double d = exact_delta(v, 0, g.n - 1);
+                    const double d = exact_delta(v, g.n, 0, g.n - 1);
                     if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
                 }
                 wave_best(e, idx);
@@ -811,7 +827,7 @@ __device__ void select_cached(const View<T>& v, const Geo& g, int tid, bool need
             }
         });
         if (tid == 0) {
-            const double d = exact_delta(v, 0, g.n - 1);
+            const double d = exact_delta(v, g.n, 0, g.n - 1);
             if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
         }
         block_best(ctl, tid, g.nt, e, idx);
@@ -842,7 +858,7 @@ __device__ void select_cached(const View<T>& v, const Geo& g, int tid, bool need
                 if (better(d, di, e, idx)) { e = d; idx = di; }
             }
             if (tid == 0) {
-                const double d = exact_delta(v, 0, g.n - 1);
+                const double d = exact_delta(v, g.n, 0, g.n - 1);
                 if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
             }
             block_best(ctl, tid, g.nt, e, idx);
@@ -917,26 +933,64 @@ __device__ __forceinline__ void put_e(const View<T>& v, const Geo& g, int p, flo
 // reverse tour[i+1..j] (two_opt.py:42) and keep the filter window consistent.  Every lane first loads
 // everything its swap needs (two positions with their coordinates, two interior edges) and only then
 // writes, so the LDS round trips of the phase overlap; the caller closes the phase with a barrier.
-template <typename T, int Q>
-__device__ __forceinline__ void apply_move(const View<T>& v, const Geo& g, int tid, unsigned idx, Prof& pf)
+// The reversal of R[i+1..j] (two_opt.py:42) as a reversal of the LDS copy: LDS positions lo0 .. lo0 + len - 1
+// (mod n).  A segment longer than half the tour is replaced by its complement -- reversing either side of a
+// cycle gives the same cycle, with the opposite orientation -- and the frame (fo, fs) records how the
+// reference's array reads the LDS copy afterwards: with lo, hi the segment's LDS ends and q a position of the
+// complement, new[q] = old[lo + hi - q], so R'[k] = old'[lo + hi - (fo + fs k)]: fo' = lo + hi - fo, fs' = -fs.
+// At most n / 2 positions move (instead of up to n - 2), and with them the tiles the sweep has to recompute:
+// at most 3/4 of the pairs read a moved position (1 - (1 - L/n)^2 with L <= n / 2) instead of up to all.
+// The whole-tour reversal (0, n-1) that converged tours of a coupled group keep applying becomes a flip of fs.
+// Q == 0 (exact kernel, no filter window to save on): never folded, the frame stays the identity.
+template <int Q, typename T>
+__device__ __forceinline__ void resolve_move(View<T>& v, int n, unsigned idx, int& lo0, int& len)
 {
-    const int i = (int)(idx >> 16), j = (int)(idx & 0xffffu);
-    FINE_START(pf);
+    const unsigned u = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);      // (uniform: scalar registers)
+    const int i = (int)(u >> 16), j = (int)(u & 0xffffu);
     const int L = j - i;
-    const int h = L >> 1;                       // position swaps
-    const int he = (L - 1) >> 1;                // interior edges i+1..j-1 are mirrored (he <= h)
+    int lo = v.fs > 0 ? v.fo + i + 1 : v.fo - j;        // LDS position of the segment's first entry, in (-n, 2n)
+    lo = wrapn(lo, n);
+    lo0 = lo;
+    len = L;
+    if constexpr (Q != 0) {
+        if (2 * L > n) {
+            lo0 = wrapn(lo + L - n, n);                 // the complement starts right behind the segment
+            len = n - L;
+            int fo = v.fs > 0 ? v.fo + i + j + 1 : v.fo - i - j - 1;    // lo + hi - fo, in (-2n, 3n)
+            fo += fo < 0 ? n : 0;
+            fo -= fo >= n ? n : 0;
+            v.fo = wrapn(fo, n);
+            v.fs = -v.fs;
+        }
+    }
+}
+
+// reverse the LDS copy's positions lo0 .. lo0 + len - 1 (mod n) and keep the filter window consistent
+template <typename T, int Q>
+__device__ __forceinline__ void apply_move(const View<T>& v, const Geo& g, int tid, int lo0, int len, Prof& pf)
+{
+    const int n = g.n;
+    FINE_START(pf);
+    const int h = len >> 1;                     // position swaps
+    const int he = (len - 1) >> 1;              // the interior edges are mirrored (he <= h)
     for (int k = tid; k < h; k += g.nt) {
-        const int p = i + 1 + k, p2 = j - k;
+        int p = lo0 + k, p2 = lo0 + len - 1 - k;
+        p -= p >= n ? n : 0;
+        p2 -= p2 >= n ? n : 0;
         const uint16_t ta = v.tour[p], tb = v.tour[p2];
         if constexpr (Q != 0) {
+            const int p2m = p2 == 0 ? n - 1 : p2 - 1;       // the edge in front of p2
             const int sp = slot<Q>(p), sp2 = slot<Q>(p2);
             const float ax = v.Xq[sp].x, ay = v.Yq[sp].x, bx = v.Xq[sp2].x, by = v.Yq[sp2].x;
             const bool ed = k < he;
             float ea = 0.f, eb = 0.f, lx = 0.f, ly = 0.f, rx = 0.f, ry = 0.f;
-            if (ed) { ea = v.Eq[sp].x; eb = v.Eq[slot<Q>(p2 - 1)].x; }
-            if (k == 0) {                       // p = i+1, p2 = j: the neighbours outside the segment
-                lx = v.Xq[slot<Q>(i)].x; ly = v.Yq[slot<Q>(i)].x;
-                rx = v.Xq[slot<Q>(j + 1)].x; ry = v.Yq[slot<Q>(j + 1)].x;
+            int pl = 0;
+            if (ed) { ea = v.Eq[sp].x; eb = v.Eq[slot<Q>(p2m)].x; }
+            if (k == 0) {                       // p, p2 are the ends: the neighbours outside the segment
+                pl = p == 0 ? n - 1 : p - 1;
+                const int pr = p2 == n - 1 ? 0 : p2 + 1;
+                lx = v.Xq[slot<Q>(pl)].x; ly = v.Yq[slot<Q>(pl)].x;
+                rx = v.Xq[slot<Q>(pr)].x; ry = v.Yq[slot<Q>(pr)].x;
             }
             v.tour[p] = tb;
             v.tour[p2] = ta;
@@ -944,11 +998,11 @@ __device__ __forceinline__ void apply_move(const View<T>& v, const Geo& g, int t
             put_xy<Q>(v, g, p2, ax, ay);
             if (ed) {
                 put_e<Q>(v, g, p, eb);
-                put_e<Q>(v, g, p2 - 1, ea);
+                put_e<Q>(v, g, p2m, ea);
             }
             if (k == 0) {                       // the two new boundary edges
-                put_e<Q>(v, g, i, dist32(lx, ly, bx, by));
-                put_e<Q>(v, g, j, dist32(ax, ay, rx, ry));
+                put_e<Q>(v, g, pl, dist32(lx, ly, bx, by));
+                put_e<Q>(v, g, p2, dist32(ax, ay, rx, ry));
             }
         } else {
             v.tour[p] = tb;
@@ -1218,6 +1272,8 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
         __syncthreads();
         const int flags = ctl->flags;
         v.X = g.xlds ? xl : X;
+        v.fo = 0;                               // the staged copy IS the reference's array
+        v.fs = 1;
         if (flags != 0) {                       // invalid input: tour untouched (uniform branch)
             if (tid == 0 && g.wc == 0) {
                 if (p.status) p.status[tk] = flags;
@@ -1340,9 +1396,11 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
             // (cached path: select_cached / the cluster exchange ended with the barrier after which nobody
             //  reads the window any more)
             FINE_START(pf);
-            apply_move<T, Q>(v, g, tid, idx, pf);               // phase A
+            int lo0, len;
+            resolve_move<Q>(v, n, idx, lo0, len);               // which side of the cycle; frame update
+            apply_move<T, Q>(v, g, tid, lo0, len, pf);          // phase A
             if constexpr (Q != 0) {
-                if (cached) mark_touched<CL>(v, g, tid, idx);
+                if (cached) mark_touched<CL>(v, g, tid, lo0, len);
             }
             FINE(pf, 0);                                        // marking + compaction
             __syncthreads();
@@ -1376,7 +1434,7 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
             return;
         }
         if (CL && g.wc != 0) continue;          // every workgroup holds the same tour; the first writes it
-        for (int k = tid; k <= n; k += nt) gt[k] = (int64_t)v.tour[k];
+        for (int k = tid; k <= n; k += nt) gt[k] = (int64_t)v.tour[ipos(v, n, k)];     // R[k], through the frame
         if (tid == 0) {
             p.iters[tk] = it;
             if (p.work_sweeps) p.work_sweeps[tk] += sweeps;
