@@ -75,40 +75,52 @@ struct CView {
     int rbase;              // tour position (unwrapped) of local row 0
     int rs0, gp0;           // first row segment / lane group of this workgroup
     int coff;               // column index of this workgroup's first lane group relative to its row (sh: 2*gp0)
+    int fo, fs;             // frame of the LDS tour against the reference's array (View::fo / fs, resolve_move)
 };
 
+// p in [0, n]: position n is position 0 of the cycle
 template <typename T>
-__device__ __forceinline__ void scaled_pos(const CView<T>& v, int p, float& x, float& y)
+__device__ __forceinline__ void scaled_pos(const CView<T>& v, int n, int p, float& x, float& y)
 {
-    const int node = v.tour[p];
+    const int node = v.tour[p >= n ? p - n : p];
     x = (float)(((double)v.X[2 * node] - v.cx) * v.sc);
     y = (float)(((double)v.X[2 * node + 1] - v.cy) * v.sc);
 }
 
-// (re)build the filter entries whose tour position is in [lo, hi] (coordinates) / [elo, ehi]
-// (edge lengths); positions are taken modulo n
+// is position p (in [0, n)) one of the `count` cyclic positions that start at `start` (in [0, n))?
+__device__ __forceinline__ bool in_cyclic(int p, int start, int count, int n)
+{
+    int d = p - start;
+    d += d < 0 ? n : 0;
+    return d < count;
+}
+
+// (re)build the filter entries whose LDS tour position is one of the `len` cyclic positions from lo0
+// (coordinates) / one of the len + 1 positions from lo0 - 1 (edge lengths: the edges in front of, inside and
+// behind the reversed range).  lo0 in [0, n); len = n: everything.
 template <typename T>
-__device__ void stage_c(const CView<T>& v, const CGeo& g, int tid, int lo, int hi, int elo, int ehi)
+__device__ void stage_c(const CView<T>& v, const CGeo& g, int tid, int lo0, int len)
 {
     const int n = g.n;
+    const int e0 = lo0 == 0 ? n - 1 : lo0 - 1, elen = len + 1;
     for (int k = tid; k < 4 * g.Qw; k += g.nt) {
         const int il = k >> 2, u = k & 3, sl = u * g.Qw + il;
         const int w = 4 * (v.ilo + il) + u;
         const int pa = w % n;
-        if (pa >= lo && pa <= hi) { float x, y; scaled_pos(v, pa, x, y); v.Xc[sl] = x; v.Yc[sl] = y; }
-        if (pa >= elo && pa <= ehi) {
+        if (in_cyclic(pa, lo0, len, n)) { float x, y; scaled_pos(v, n, pa, x, y); v.Xc[sl] = x; v.Yc[sl] = y; }
+        if (in_cyclic(pa, e0, elen, n)) {
             float x0, y0, x1, y1;
-            scaled_pos(v, pa, x0, y0); scaled_pos(v, pa + 1, x1, y1);
+            scaled_pos(v, n, pa, x0, y0); scaled_pos(v, n, pa + 1, x1, y1);
             v.Ec[sl] = dist32(x0, y0, x1, y1);
         }
     }
     if (g.sh) return;
     for (int k = tid; k < g.rowsw + 8; k += g.nt) {
         const int pp = (v.rbase + k) % n;
-        if (pp >= lo && pp <= hi) { float x, y; scaled_pos(v, pp, x, y); v.RX[k] = x; v.RY[k] = y; }
-        if (pp >= elo && pp <= ehi) {
+        if (in_cyclic(pp, lo0, len, n)) { float x, y; scaled_pos(v, n, pp, x, y); v.RX[k] = x; v.RY[k] = y; }
+        if (in_cyclic(pp, e0, elen, n)) {
             float x0, y0, x1, y1;
-            scaled_pos(v, pp, x0, y0); scaled_pos(v, pp + 1, x1, y1);
+            scaled_pos(v, n, pp, x0, y0); scaled_pos(v, n, pp + 1, x1, y1);
             v.RE[k] = dist32(x0, y0, x1, y1);
         }
     }
@@ -255,7 +267,7 @@ __device__ __forceinline__ float part_min_c(const CView<T>& v, const CGeo& g, in
 // each lane marks the touched groups of its own unit in closed form (rows, columns), the ids are compacted into a list and processed evenly by all lanes, then
 // every lane reduces the cached minima of its unit exactly as the full sweep would.
 template <typename T>
-__device__ __forceinline__ void sweep_c(const CView<T>& v, const CGeo& g, int tid, unsigned last,
+__device__ __forceinline__ void sweep_c(const CView<T>& v, const CGeo& g, int tid, unsigned last, int lo0, int len,
                                         float& a1, float& a2, unsigned& chunk, Prof& pf)
 {
     Ctl* ctl = v.ctl;
@@ -263,7 +275,10 @@ __device__ __forceinline__ void sweep_c(const CView<T>& v, const CGeo& g, int ti
     bool full = !g.inc || last == kFullSweep;
     FINE_START(pf);
     if (!full) {
-        const int i = (int)(last >> 16), j = (int)(last & 0xffffu);
+        // window positions [i, j] (+ k n) read changed values: the reversed LDS range lo0 .. lo0 + len - 1 and the
+        // edge in front of it; the earliest copy that can reach the window starts below 0 when the range wraps
+        int i = lo0 - 1, j = lo0 + len - 1;
+        if (j >= g.n) { i -= g.n; j -= g.n; }
         const int gpl = tid % g.GPw, sl = tid / g.GPw;
         const bool own = tid < units && v.gp0 + gpl < g.GP;
         unsigned long long mask = 0ull;
@@ -349,13 +364,26 @@ __device__ __forceinline__ void sweep_c(const CView<T>& v, const CGeo& g, int ti
     FINE(pf, 3);
 }
 
+// exact delta of the REFERENCE pair (i, j), read through the frame
 template <typename T>
-__device__ __forceinline__ double exact_delta_c(const CView<T>& v, int i, int j)
+__device__ __forceinline__ double exact_delta_c(const CView<T>& v, int n, int i, int j)
 {
     View<T> w;
     w.tour = v.tour;
     w.X = v.X;
-    return exact_delta(w, 1 << 30, i, j);       // identity frame: positions are used as they are
+    w.fo = v.fo;
+    w.fs = v.fs;
+    return exact_delta(w, n, i, j);
+}
+
+// reference index of the pair of LDS edges r, c (pair_index of the one-workgroup kernel)
+template <typename T>
+__device__ __forceinline__ unsigned pair_index_c(const CView<T>& v, int n, int r, int c)
+{
+    const int er = v.fs > 0 ? wrapn(r - v.fo, n) : wrapn(v.fo - 1 - r, n);
+    const int ec = v.fs > 0 ? wrapn(c - v.fo, n) : wrapn(v.fo - 1 - c, n);
+    const int i = er < ec ? er : ec, j = er < ec ? ec : er;
+    return ((unsigned)i << 16) | (unsigned)j;
 }
 
 // exact value of pair `pr` (0..31) of macro step `m` of local unit `u`; false for padding units
@@ -371,9 +399,8 @@ __device__ __forceinline__ bool eval_chunk_pair_c(const CView<T>& v, const CGeo&
     const int c0 = r0 + 2 + 4 * gi;
     const int a = (pr >> 2) & 3, q = pr & 3;
     const int r = (r0 + a) % g.n, c = (c0 + a + q) % g.n;
-    const int i = r < c ? r : c, j = r < c ? c : r;
-    e = exact_delta_c(v, i, j);
-    idx = ((unsigned)i << 16) | (unsigned)j;
+    idx = pair_index_c(v, g.n, r, c);
+    e = exact_delta_c(v, g.n, (int)(idx >> 16), (int)(idx & 0xffffu));
     return true;
 }
 
@@ -409,14 +436,14 @@ __device__ __forceinline__ void eval_group_c(const CView<T>& v, const CGeo& g, i
 // best move of this workgroup's tile: e = min(0, min exact delta), idx packed; valid in all threads
 template <typename T>
 __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool first_wg, unsigned last,
-                               double& e, unsigned& idx, Prof& pf)
+                               int lo0, int len, double& e, unsigned& idx, Prof& pf)
 {
     Ctl* ctl = v.ctl;
     float a1, a2;
     unsigned chunk;
     unsigned long long t0 = 0;
     if (pf.on) t0 = clock64();
-    sweep_c(v, g, tid, last, a1, a2, chunk, pf);
+    sweep_c(v, g, tid, last, lo0, len, a1, a2, chunk, pf);
     if (pf.on) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
     const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
     const float wm = wave_min(a1);
@@ -441,7 +468,7 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
             eval_group_c(v, g, __builtin_amdgcn_readlane((int)chunk, src), thr, lane, e, idx);
         }
         if (first_wg && tid == 32) {        // the pair (0, n-1), once per tour
-            const double d = exact_delta_c(v, 0, g.n - 1);
+            const double d = exact_delta_c(v, g.n, 0, g.n - 1);
             if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
         }
         wave_best(e, idx);
@@ -502,7 +529,7 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
             }
         }
         if (first_wg && tid == 0) {
-            const double d = exact_delta_c(v, 0, g.n - 1);
+            const double d = exact_delta_c(v, g.n, 0, g.n - 1);
             if (better(d, (unsigned)(g.n - 1), e, idx)) { e = d; idx = (unsigned)(g.n - 1); }
         }
         block_best(ctl, tid, g.nt, e, idx);
@@ -610,7 +637,9 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
             if (wc == 0 && tid == 0) { if (p.status) p.status[tk] = flags; p.iters[tk] = 0; }
             continue;
         }
-        stage_c(v, g, tid, 0, n - 1, 0, n - 1);
+        v.fo = 0;                               // the staged copy IS the reference's array
+        v.fs = 1;
+        stage_c(v, g, tid, 0, n);
         __syncthreads();
 
         // ---- improvement loop (independent termination) ------------------------------------------
@@ -620,10 +649,11 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
         Prof pf = make_prof(p.stamps);
         unsigned long long t_x = 0, t_tour = pf.on ? clock64() : 0;
         unsigned last = kFullSweep;             // reversal applied since the previous sweep
+        int lo0 = 0, len = 0;                   // ... as the range of LDS positions it moved
         for (;;) {
             double e;
             unsigned idx, fl = 0;
-            find_best_tile(v, g, tid, wc == 0, last, e, idx, pf);
+            find_best_tile(v, g, tid, wc == 0, last, lo0, len, e, idx, pf);
             ++sweeps;
             unsigned long long tb = pf.on ? clock64() : 0;
             unsigned myflags = 0;
@@ -635,16 +665,27 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
             FINE(pf, 11);                                                    // cluster exchange
             if (pf.on) { const unsigned long long t1 = clock64(); t_x += t1 - tb; tb = t1; }
             if (!(e < -1.0e-6)) break;                                       // two_opt.py:40
-            const int i = (int)(idx >> 16), j = (int)(idx & 0xffffu);
-            const int h = (j - i) >> 1;
-            for (int k = tid; k < h; k += nt) {                              // two_opt.py:42
-                const uint16_t a = v.tour[i + 1 + k], b = v.tour[j - k];
-                v.tour[i + 1 + k] = b;
-                v.tour[j - k] = a;
+            // two_opt.py:42, on the shorter side of the cycle (resolve_move: the frame records the orientation)
+            {
+                View<T> w;
+                w.fo = v.fo;
+                w.fs = v.fs;
+                resolve_move<1>(w, n, idx, lo0, len);
+                v.fo = w.fo;
+                v.fs = w.fs;
+            }
+            const int h = len >> 1;
+            for (int k = tid; k < h; k += nt) {
+                int pa = lo0 + k, pb = lo0 + len - 1 - k;
+                pa -= pa >= n ? n : 0;
+                pb -= pb >= n ? n : 0;
+                const uint16_t a = v.tour[pa], b = v.tour[pb];
+                v.tour[pa] = b;
+                v.tour[pb] = a;
             }
             __syncthreads();
             FINE(pf, 8);                                                     // tour reversal
-            stage_c(v, g, tid, i + 1, j, i, j);
+            stage_c(v, g, tid, lo0, len);
             FINE(pf, 9);                                                     // restaging of the filter copy
             __syncthreads();
             FINE(pf, 10);
@@ -684,7 +725,7 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
             return;
         }
         if (wc == 0) {
-            for (int k = tid; k <= n; k += nt) gt[k] = (int64_t)v.tour[k];
+            for (int k = tid; k <= n; k += nt) gt[k] = (int64_t)v.tour[wrapn(v.fo + v.fs * k, n)];   // R[k]
             if (tid == 0) {
                 p.iters[tk] = it;
                 if (p.work_sweeps) p.work_sweeps[tk] += sweeps;
