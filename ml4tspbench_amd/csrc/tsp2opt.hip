@@ -257,6 +257,7 @@ Plan make_plan_nt(const Opts& o, int n, int dtype, int cs, int nt_cap)
         const int G = 2 * GP;
         const int GPl = (GP + cs - 1) / cs;             // lane groups per workgroup
         g.GPl = GPl;
+        g.inv_gpl = 1.0f / (float)(GPl > 0 ? GPl : 1);
         // every walked diagonal d = 2..8GP+1 must be a valid pair distance: d <= n-2
         if (GP >= 1 && 8 * GP + 1 <= n - 2) {
             const int R = (n + 3) / 4;                  // macro-step rows needed

@@ -30,7 +30,12 @@ struct Geo {                          // launch geometry of the filter sweep (ho
     int inc;                          // tile-minimum cache + incremental sweeps
     int lcap;                         // capacity of the changed-tile list
     float eps2;                       // 2*eps of the filter, in scaled units
+    float inv_gpl;                    // 1 / GPl: unit -> (row segment, lane group) without an integer division
 };
+
+// u / GPl for 0 <= u < 2048, GPl <= 255 (exact: (u + 0.5) / GPl is at least 0.5 / 255 away from an integer,
+// the float product is off by less than 1e-3 of that)
+__device__ __forceinline__ int div_gpl(const Geo& g, int u) { return (int)(((float)u + 0.5f) * g.inv_gpl); }
 
 struct Params {
     const void* points;
@@ -110,6 +115,7 @@ struct Ctl {                          // LDS control block (first bytes of dynam
     unsigned bestIdx;
     float spd;                        // cached filter value of the pair (0, n-1) (thread 0; find_best)
     double cx, cy, sc;
+    double isc;                       // 1 / sc (a power of two, exact)
 };
 
 // ------------------------------------------------------------------------------------------

@@ -104,7 +104,7 @@ __device__ __forceinline__ void filter_sweep(const v2f* Xq, const v2f* Yq, const
     chunk = 0;
     const int units = g.GPl * g.NS, MS2 = g.MS >> 1;
     for (int u = tid; u < units; u += g.nt) {
-        const int gpl = u % g.GPl, s = u / g.GPl;
+        const int s = div_gpl(g, u), gpl = u - s * g.GPl;
         const int gp = CL ? g.wc + g.CS * gpl : gpl;
         if constexpr (CL) {
             if (gp >= g.GP) continue;                       // padding of the last workgroups
@@ -173,8 +173,9 @@ __device__ __forceinline__ Unit lane_unit(const Geo& g, int tid)
 {
     Unit un{-1, 0, 0};
     if (tid < g.GPl * g.NS) {
-        un.gpl = tid % g.GPl;
-        un.rq0 = (tid / g.GPl) * (g.MS >> 1);
+        const int s = div_gpl(g, tid);
+        un.gpl = tid - s * g.GPl;
+        un.rq0 = s * (g.MS >> 1);
         const int gp = CL ? g.wc + g.CS * un.gpl : un.gpl;
         if (!CL || gp < g.GP) un.gp = gp;
     }
@@ -450,7 +451,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
         sweep<Q, CL>(v, g, tid, a1, a2, chunk, pf);
         if (pf.on) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
         const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
-        const float wm = wave_min(a1);
+        const float wm = wave_min_ordered(a1);       // (filter values are never NaN: scaled coordinates are finite)
         float m = wm;
         if (nw > 1) {                                       // one-wave workgroups need no LDS round trip
             if (lane == 0) ctl->wmin[wv] = wm;
@@ -518,7 +519,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
             // wave result: the minimum value and, when every in-window pair of the wave is the same
             // pair, that pair (otherwise the index is not used: `wother` sends the search to stage 2)
             const unsigned long long hm = __ballot(fidx != 0xffffffffu);
-            double wd = (double)wave_min(fd);
+            double wd = (double)wave_min_ordered(fd);
             unsigned widx = 0xffffffffu;
             if (hm) widx = (unsigned)__builtin_amdgcn_readlane((int)fidx, __ffsll((long long)hm) - 1);
             const bool wother = __ballot(multi || (fidx != 0xffffffffu && fidx != widx)) != 0ull;
@@ -549,7 +550,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
             FINE(pf, 6);                                    // wave + workgroup reduction of the fp32 stage
             if (!amb) {
                 if (unique && (float)bd < -thr_scale - eps) {           // certain improving move
-                    e = ((double)(float)bd + (double)eps) / ctl->sc;     // an upper bound, < -1e-6
+                    e = ((double)(float)bd + (double)eps) * ctl->isc;   // an upper bound, < -1e-6
                     idx = bi;
                     if (pf.on) pf.select += clock64() - t0;
                     return;
@@ -666,7 +667,7 @@ __device__ __forceinline__ int for_each_candidate_tile(const View<T>& v, const G
             while (ub) {
                 const int u = 256 * c + 4 * __builtin_amdgcn_readfirstlane(__ffsll((long long)ub) - 1) + k;
                 ub &= ub - 1;
-                const int s = u / g.GPl, gpl = u - s * g.GPl;
+                const int s = div_gpl(g, u), gpl = u - s * g.GPl;
                 const int rq0 = s * MS2;
                 const unsigned cm = v.Mc[(rq0 + (lane < MS2 ? lane : MS2 - 1)) * g.GPl + gpl];
                 unsigned long long tb = __ballot(lane < MS2 && cm <= kthr);
@@ -721,7 +722,7 @@ __device__ void select_cached(const View<T>& v, const Geo& g, int tid, bool need
     FINE_START(pf);
     if (mine) {
         const UnitMinima um = load_unit_minima(v, g, lane);     // one LDS round trip together with sc / spd
-        const double scale = ctl->sc;
+        const double scale = ctl->sc, iscale = ctl->isc;
         const float spd = ctl->spd;
         const float thr_scale = (float)(1.0e-6 * scale);
         float m;
@@ -775,14 +776,14 @@ __device__ void select_cached(const View<T>& v, const Geo& g, int tid, bool need
                 }
                 FINE(pf, 5);                            // fp32 re-evaluation of the candidate tiles
                 const unsigned long long hm = __ballot(fidx != 0xffffffffu);
-                const float wd = wave_min(fd);
+                const float wd = wave_min_ordered(fd);
                 unsigned widx = 0xffffffffu;
                 if (hm) widx = (unsigned)__builtin_amdgcn_readlane((int)fidx, __ffsll((long long)hm) - 1);
                 const bool wother = __ballot(multi || (fidx != 0xffffffffu && fidx != widx)) != 0ull;
                 const bool unique = !wother && widx != 0xffffffffu;
                 code = 1;
                 if (unique && wd < -thr_scale - eps) {                  // certain improving move
-                    e = ((double)wd + (double)eps) / scale;             // an upper bound, < -1e-6
+                    e = ((double)wd + (double)eps) * iscale;            // an upper bound, < -1e-6
                     idx = widx;
                     code = 0;
                 } else if (!need_exact_sign && m > -thr_scale + eps &&
@@ -1266,8 +1267,10 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
             const double half = fmax(0.5 * (mxx - mnx), 0.5 * (mxy - mny));
             int ex = 0;
             double sc = 1.0;
-            if (half > 0.0 && half < INFINITY) { (void)frexp(half, &ex); sc = ldexp(1.0, -ex); }
+            double isc = 1.0;
+            if (half > 0.0 && half < INFINITY) { (void)frexp(half, &ex); sc = ldexp(1.0, -ex); isc = ldexp(1.0, ex); }
             ctl->sc = sc;                       // half * sc in [0.5, 1)
+            ctl->isc = isc;
         }
         __syncthreads();
         const int flags = ctl->flags;
