@@ -436,7 +436,7 @@ CPlan make_cluster_plan(const Opts& o, int n, int dtype, int cs_cap, bool smalle
             if (cs < 2 || cd > GP || cr > R) continue;
             const int GPw = (GP + cd - 1) / cd;
             const int rmw = (R + cr - 1) / cr;          // macro rows per row band
-            for (int nt : {256, 512, 768}) {            // <= 768 threads: 3 waves/SIMD, no spills
+            for (int nt : {768, 512, 256}) {            // <= 768 threads: 3 waves/SIMD, no spills; ties go to the larger
                 if (n < 700 && nt != 256) continue;
                 int NSw = nt / GPw;
                 if (NSw < 1) NSw = 1;
@@ -481,7 +481,11 @@ CPlan make_cluster_plan(const Opts& o, int n, int dtype, int cs_cap, bool smalle
                 // measured: incremental sweeps recompute a little under half of the pairs -- of the SLOWEST
                 // workgroup: with row bands (cr > 1) one band usually lies inside the reversed segment and
                 // recomputes nearly everything while the others wait for it
-                const double t_iter = (K ? (cr > 1 ? 0.8 : 0.55) : 1.0) * 0.4 * MS * passes * wps + 12.0 + 0.15 * cs;
+                // shared rows with an odd number of diagonal bands interleave the lane groups over the workgroups
+                // (CView::gstr): equal work everywhere; contiguous diagonal bands wait for the band of the longest
+                // diagonals (measured at TSP-10000, 16 bands: a fifth of the iteration)
+                const bool il = shared && (cd & 1) && cd > 1;
+                const double t_iter = (K ? (cr > 1 ? 0.8 : (il || cd == 1 ? 0.55 : 0.68)) : 1.0) * 0.4 * MS * passes * wps + 12.0 + 0.15 * cs;
                 const double cost = smallest ? t_iter * cs : t_iter;    // total WG-time vs latency
                 if (cost >= best_cost) continue;
                 lds += cache;
@@ -489,6 +493,7 @@ CPlan make_cluster_plan(const Opts& o, int n, int dtype, int cs_cap, bool smalle
                 g.n = n; g.nt = nt; g.GP = GP; g.CS = cs; g.CR = cr; g.CD = cd;
                 g.GPw = GPw; g.NSw = NSw; g.MS = MS; g.Qw = Qw; g.rowsw = rowsw;
                 g.sh = shared ? 1 : 0; g.wrapg = wrap ? n / 4 : 0x3fffffff;
+                g.il = il ? 1 : 0;
                 g.K = K ? K : 1; g.Ksh = K ? Ksh : 2; g.NG = NG; g.inc = K ? 1 : 0; g.lcap = lcap;
                 {   // parts of at most 2^part_sh macro steps (the restart of a part costs about one macro step)
                     int psh = 0;

@@ -33,6 +33,7 @@ struct CGeo {
     int GPw, NSw, MS;       // per workgroup: lane groups, row segments; macro steps per segment
     int Qw;                 // entries per sub-array of the compact column arrays
     int sh;                 // rows read from the column arrays (CR = 1: whole tour in every workgroup)
+    int il;                 // sh and CD odd: lane groups interleaved over the diagonal bands (CView::gstr)
     int wrapg;              // sh: window groups wrap at this index (n / 4), or a huge value (no wrap)
     int rowsw;              // row positions of the band = 4*NSw*MS
     int xlds;
@@ -74,6 +75,14 @@ struct CView {
     int ilo;                // window group of local column index 0
     int rbase;              // tour position (unwrapped) of local row 0
     int rs0, gp0;           // first row segment / lane group of this workgroup
+    int gstr;               // local lane group gpl is lane group gp0 + gstr * gpl of the tour.  Row bands (local column
+                            // window): contiguous, gstr = 1.  Shared rows (whole tour in LDS) with an ODD number of
+                            // diagonal bands: INTERLEAVED, gp0 = cd, gstr = CD -- a pair on diagonal d reads a moved
+                            // position for (L + min(d, L)) / n of its rows, so a contiguous band of short diagonals has
+                            // about half the work of a band of long ones and the cluster waits for the slowest;
+                            // interleaved, every workgroup sees the same mix.  (Odd: adjacent lanes' column operands are
+                            // then 2 * CD = 2 (mod 4) floats apart, the same 2-way LDS bank pattern as contiguous groups;
+                            // an even CD puts 4, 8, ... lanes on one bank: CD = 16 is a 32-way conflict)
     int coff;               // column index of this workgroup's first lane group relative to its row (sh: 2*gp0)
     int fo, fs;             // frame of the LDS tour against the reference's array (View::fo / fs, resolve_move)
 };
@@ -224,13 +233,13 @@ __device__ __forceinline__ void filter_sweep_c(const CView<T>& v, const CGeo& g,
     const int units = g.GPw * g.NSw;
     for (int u = tid; u < units; u += g.nt) {
         const int gpl = u % g.GPw, sl = u / g.GPw;
-        if (v.gp0 + gpl >= g.GP) continue;              // padding of the last diagonal band
+        if (v.gp0 + v.gstr * gpl >= g.GP) continue;              // padding of the last diagonal band
         unsigned id = (unsigned)u * (unsigned)g.NG;
         unsigned* mc = v.Mc ? v.Mc + u : nullptr;
         float gm = INFINITY;
         int k = 0;
         const int K = g.K;
-        walk_c(v, g, 4 * sl * g.MS, sl * g.MS + 2 * gpl + 1 + v.coff, g.MS, [&](float mm) {
+        walk_c(v, g, 4 * sl * g.MS, sl * g.MS + 2 * v.gstr * gpl + 1 + v.coff, g.MS, [&](float mm) {
             gm = __builtin_fminf(gm, mm);
             if (++k == K) {
                 if (mc) { *mc = fkey(gm); mc += units; }
@@ -256,7 +265,7 @@ __device__ __forceinline__ float part_min_c(const CView<T>& v, const CGeo& g, in
     int cnt = g.MS - m0 < P ? g.MS - m0 : P;
     float gm = INFINITY;
     if (cnt > 0)
-        walk_c(v, g, 4 * (sl * g.MS + m0), sl * g.MS + 2 * gpl + 1 + m0 + v.coff, cnt,
+        walk_c(v, g, 4 * (sl * g.MS + m0), sl * g.MS + 2 * v.gstr * gpl + 1 + m0 + v.coff, cnt,
                [&](float mm) { gm = __builtin_fminf(gm, mm); });
     return gm;
 }
@@ -280,11 +289,11 @@ __device__ __forceinline__ void sweep_c(const CView<T>& v, const CGeo& g, int ti
         int i = lo0 - 1, j = lo0 + len - 1;
         if (j >= g.n) { i -= g.n; j -= g.n; }
         const int gpl = tid % g.GPw, sl = tid / g.GPw;
-        const bool own = tid < units && v.gp0 + gpl < g.GP;
+        const bool own = tid < units && v.gp0 + v.gstr * gpl < g.GP;
         unsigned long long mask = 0ull;
         if (own) {
             const int rb = v.rbase + 4 * sl * g.MS;                 // window position of the unit's first row
-            const int ca = rb + 2 + 8 * (v.gp0 + gpl);              // ... of its first column (stream A)
+            const int ca = rb + 2 + 8 * (v.gp0 + v.gstr * gpl);              // ... of its first column (stream A)
             const int wmax = ca + (g.NG << g.Ksh) + 8;
             // group q reads rows [rb + Sq, rb + Sq + S], columns [ca + Sq, ca + Sq + S + 7], S = 4K
             for (int lo = i, hi = j; lo <= wmax; lo += g.n, hi += g.n) {
@@ -392,7 +401,7 @@ __device__ __forceinline__ bool eval_chunk_pair_c(const CView<T>& v, const CGeo&
                                                   double& e, unsigned& idx)
 {
     const int gpl = u % g.GPw, sl = u / g.GPw;
-    const int gp = v.gp0 + gpl;
+    const int gp = v.gp0 + v.gstr * gpl;
     if (gp >= g.GP) return false;
     const int gi = 2 * gp + (pr >> 4);
     const int r0 = 4 * ((v.rs0 + sl) * g.MS + m);
@@ -417,7 +426,7 @@ __device__ __forceinline__ void eval_group_c(const CView<T>& v, const CGeo& g, i
         float mm = INFINITY;
         if (lane < g.K && m0 + lane < g.MS) {
             const int gpl = u % g.GPw, sl = u / g.GPw, m = m0 + lane;
-            walk_c(v, g, 4 * (sl * g.MS + m), sl * g.MS + 2 * gpl + 1 + m + v.coff, 1, [&](float x) { mm = x; });
+            walk_c(v, g, 4 * (sl * g.MS + m), sl * g.MS + 2 * v.gstr * gpl + 1 + m + v.coff, 1, [&](float x) { mm = x; });
         }
         sm = __ballot(mm <= thr);
     }
@@ -501,7 +510,7 @@ __device__ void find_best_tile(const CView<T>& v, const CGeo& g, int tid, bool f
             const int units = g.GPw * g.NSw, groups = units * g.NG;
             for (int t = tid; t < groups; t += g.nt) {
                 const int q = t / units, u = t - q * units;
-                if (v.Mc[t] <= fkey(thr) && v.gp0 + u % g.GPw < g.GP) {
+                if (v.Mc[t] <= fkey(thr) && v.gp0 + v.gstr * (u % g.GPw) < g.GP) {
                     const unsigned pos = atomicAdd(&ctl->nlist, 1u);
                     if (pos < (unsigned)g.lcap) v.list[pos] = (uint16_t)(u * g.NG + q);
                 }
@@ -568,7 +577,8 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
     }
     T* xl = reinterpret_cast<T*>(smem + off);
     v.rs0 = cr * g.NSw;
-    v.gp0 = cd * g.GPw;
+    v.gp0 = g.il ? cd : cd * g.GPw;
+    v.gstr = g.il ? g.CD : 1;
     v.ilo = g.sh ? 0 : v.rs0 * g.MS + 2 * v.gp0;
     v.coff = g.sh ? 2 * v.gp0 : 0;
     v.rbase = 4 * v.rs0 * g.MS;
