@@ -229,6 +229,31 @@ int tsp2opt_local_search(const double* points, int64_t* tours, int32_t* rounds_o
                          int32_t device, void* hip_stream);
 
 /*
+ * tsp2opt_gls_rounds -- (regret) guided local search, whole outer rounds on the device, for every tour of a batch.
+ * Replaces the loop body of tsp_gls (search/local_search.py:176-231; the same loop is ML4TSPNARGuidedLS._local_search,
+ * ml4tsp-library/ml4tsp/nar/local_search/guided_ls.py:23-88): per round the perturbation loop -- the tour edge of
+ * maximum utility regret / (1 + penalty) (first among equals, :192-202) is penalised (:206-208) and get_two_opt_tour /
+ * get_relocate_tour run with its end nodes as fixed rows under the weights dist + k * penalty (:209-223) until
+ * `perturbation_moves` moves were made -- then local_search under plain distances (:226) and the comparison that
+ * keeps the best tour (:227-229).  The reference's wall-clock test (:187) is the caller's: `rounds` rounds per call.
+ *   tours      (num_tours, n+1) int64: the CURRENT tour of every search, in / out
+ *   best_tours (num_tours, n+1) int64, best_cost (num_tours) double: best tour so far and its cost, in / out
+ *   guide_k    (num_tours) double: k = 0.1 * initial cost / n (:179), written by the init call, read afterwards
+ *   penalty    (num_tours, n, n) double, in / out (zeros before the init call)
+ *   regret     (num_tours / tours_per_map, n, n) double: max(-heat, 0) (:167,177), shared by tours_per_map tours
+ *   init != 0  first do what precedes the loop (:178-182): k, a first local_search, best = its result
+ *   status_out TSP2OPT_ST_BAD_INDEX (tour untouched), TSP2OPT_ST_CAPPED (a perturbation loop found no guided move
+ *              100 000 times in a row, where the reference would spin for ever), or 0
+ * Exact double arithmetic in the reference's operation order: tours are bit-identical to the reference's for the
+ * same number of rounds.  One workgroup per tour; tour and coordinates stay in LDS for the whole call.
+ */
+int tsp2opt_gls_rounds(const double* points, int64_t* tours, int64_t* best_tours, double* best_cost,
+                       double* guide_k, double* penalty, const double* regret, int32_t* status_out,
+                       int64_t num_tours, int32_t n, int32_t tours_per_instance, int32_t tours_per_map,
+                       int32_t perturbation_moves, int32_t rounds, int32_t init, int32_t device,
+                       void* hip_stream);
+
+/*
  * tsp2opt_sqrt_check -- numerics self-test used by the GPU test-suite: out[k] = sqrt(in[k])
  * computed with the exact device routine the delta evaluation uses (dtype as above).  Lets the
  * tests prove 0-ulp agreement with the host's correctly rounded sqrt (SURVEY.md hard part b).

@@ -15,7 +15,7 @@ from .local_search import (  # noqa: F401
     get_local_search_by_name, get_local_search_func, LOCAL_SEARCH_CLASS,
 )
 from .local_ops import (  # noqa: F401,E402
-    tsp_relocate, tsp_ls, tsp_gls, ML4TSPNARGuidedLS, ls_step_device, local_search_device,
+    tsp_relocate, tsp_ls, tsp_gls, ML4TSPNARGuidedLS, ls_step_device, local_search_device, guided_ls_device,
 )
 from .anytime import two_opt_anytime, AnytimeResult  # noqa: F401,E402
 
@@ -26,7 +26,7 @@ LOCAL_SEARCH_CLASS[("tsp", "gls")] = tsp_gls
 
 __all__ = [
     "two_opt_anytime", "AnytimeResult",
-    "tsp_relocate", "tsp_ls", "tsp_gls", "ML4TSPNARGuidedLS", "ls_step_device", "local_search_device",
+    "tsp_relocate", "tsp_ls", "tsp_gls", "ML4TSPNARGuidedLS", "ls_step_device", "local_search_device", "guided_ls_device",
     "batched_two_opt_torch", "tsp_2opt", "two_opt_device", "TwoOptResult", "evaluate_tours", "EvalResult",
     "ML4TSPNARLocalSearch", "ML4TSPNARTwoOpt", "ML4TSPARLocalSearch", "ML4TSPARTwoOpt",
     "get_local_search_by_name", "get_local_search_func", "LOCAL_SEARCH_CLASS",

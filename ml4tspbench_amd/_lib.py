@@ -43,6 +43,7 @@ SYMBOLS = (
     "tsp2opt_greedy_sparse_workspace_bytes",
     "tsp2opt_ls_step",
     "tsp2opt_local_search",
+    "tsp2opt_gls_rounds",
     "tsp2opt_sqrt_check",
     "tsp2opt_plan",
     "tsp2opt_debug_greedy_cycles",
@@ -106,6 +107,8 @@ def lib() -> ctypes.CDLL:
     L.tsp2opt_ls_step.restype = ctypes.c_int
     L.tsp2opt_local_search.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
     L.tsp2opt_local_search.restype = ctypes.c_int
+    L.tsp2opt_gls_rounds.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]
+    L.tsp2opt_gls_rounds.restype = ctypes.c_int
     L.tsp2opt_greedy_decode_sparse.argtypes = [vp, vp, vp, vp, i64, i32, i64, i32, i32, i32, vp, i64, vp]
     L.tsp2opt_greedy_decode_sparse.restype = ctypes.c_int
     L.tsp2opt_greedy_sparse_workspace_bytes.argtypes = [i64, i32, i64, i32, i32]

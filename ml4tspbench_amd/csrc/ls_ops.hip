@@ -290,6 +290,200 @@ __global__ void __launch_bounds__(256) k_ls(LsParams p)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// guided local search: whole outer rounds on the device (search/local_search.py:176-231, tsp_gls)
+// ------------------------------------------------------------------------------------------
+// One workgroup per tour keeps the tour and the coordinates in LDS for the whole call and runs, per outer
+// round, the reference's perturbation loop -- utility argmax over the tour's edges (:192-202), penalty update
+// (:206-208), the two operators with the penalised edge's end nodes as fixed rows under the guided weights
+// (:212-223) until `perturbation_moves` moves were made -- then local_search under the plain weights (:226) and
+// the cost comparison that keeps the best tour (:227-229).  Penalties, regrets and the best tour live in device
+// memory between calls; the host only decides how many rounds to run (a round count, or one round per launch
+// against the wall clock).  `init`: the part in front of the loop (:178-182): k = 0.1 * cost / n, a first
+// local_search, best = that.
+struct GlsParams {
+    const double* points;
+    int64_t* tours;             // current tour of every search, in / out
+    int64_t* best_tours;        // best tour so far, in / out
+    double* best_cost;
+    double* guide_k;
+    double* penalty;            // (T, n, n)
+    const double* regret;       // (T / tph, n, n): max(-heat, 0)
+    int32_t* status;
+    int64_t num_tours;
+    int n, tpi, tph;
+    int pm;                     // perturbation_moves
+    int rounds;
+    int init;
+    int xlds, flat;
+};
+
+// closed-tour cost exactly as TSPEvaluator.evaluate sums it (utils/evaluator.py:9-13): edge by edge in tour
+// order, in double; thread 0 sums, every thread gets the value
+__device__ double gls_cost(const LsCtx& c, double* red, int tid)
+{
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int q = 0; q < c.n; ++q) s += wgt<false>(c, c.t[q], c.t[q + 1]);
+        red[0] = s;
+    }
+    __syncthreads();
+    const double s = red[0];
+    __syncthreads();
+    return s;
+}
+
+__device__ void gls_local_search(const LsCtx& c, uint16_t* t, int tid, int nt, double* red)
+{
+    bool improved = true;
+    while (improved) {
+        improved = false;
+        for (int op = 0; op < 2; ++op) {
+            double e;
+            unsigned key;
+            ls_best<false>(c, op, -1, tid, nt, red, e, key);
+            if (e < 0.0) {
+                ls_apply(t, c.n, op, key, tid, nt);
+                improved = true;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gls(GlsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = p.n, tid = threadIdx.x, nt = blockDim.x;
+    const int64_t tk = blockIdx.x;
+    if (tk >= p.num_tours) return;
+    double* red = reinterpret_cast<double*>(smem);                  // 16 doubles
+    int* flag = reinterpret_cast<int*>(smem + 128);                 // [0] bad input, [1] position found
+    uint16_t* t = reinterpret_cast<uint16_t*>(smem + 144);
+    size_t off = 144 + ((sizeof(uint16_t) * (size_t)(n + 1) + 15) & ~(size_t)15);
+    double* xl = reinterpret_cast<double*>(smem + off);
+    const double* X = p.points + (size_t)(tk / p.tpi) * (size_t)n * 2;
+    int64_t* gt = p.tours + (size_t)tk * (size_t)(n + 1);
+    int64_t* gb = p.best_tours + (size_t)tk * (size_t)(n + 1);
+    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+    __syncthreads();
+    int bad = 0;
+    for (int q = tid; q <= n; q += nt) {
+        const int64_t v = gt[q];
+        if (v < 0 || v >= n) { bad = 1; t[q] = 0; } else t[q] = (uint16_t)v;
+    }
+    if (p.xlds)
+        for (int q = tid; q < 2 * n; q += nt) xl[q] = X[q];
+    if (bad) atomicOr(&flag[0], 1);
+    __syncthreads();
+    if (flag[0]) {                              // an entry outside [0, n): tour left untouched
+        if (tid == 0 && p.status) p.status[tk] = TSP2OPT_ST_BAD_INDEX;
+        return;
+    }
+    double* pen = p.penalty + (size_t)tk * (size_t)n * (size_t)n;
+    const double* reg = p.regret + (size_t)(tk / p.tph) * (size_t)n * (size_t)n;
+    LsCtx cp;                                   // plain weights (local_search, costs)
+    cp.t = t;
+    cp.X = p.xlds ? xl : X;
+    cp.pen = nullptr;
+    cp.k = 0.0;
+    cp.n = n;
+    cp.ewf = cp.ewr = cp.head = nullptr;
+    if (p.flat) {
+        double* tab = xl + 2 * (size_t)n;
+        cp.ewf = tab;
+        cp.ewr = tab + (n + 2);
+        cp.head = tab + 2 * (size_t)(n + 2);
+    }
+    double k, best;
+    if (p.init) {
+        const double c0 = gls_cost(cp, red, tid);
+        k = 0.1 * c0 / (double)n;                                   // local_search.py:179
+        gls_local_search(cp, t, tid, nt, red);                      // :180
+        best = gls_cost(cp, red, tid);                              // :181-182
+        __syncthreads();
+        for (int q = tid; q <= n; q += nt) gb[q] = (int64_t)t[q];
+    } else {
+        k = p.guide_k[tk];
+        best = p.best_cost[tk];
+    }
+    LsCtx cg = cp;                              // guided weights: dist + k * penalty (:209)
+    cg.pen = pen;
+    cg.k = k;
+    cg.ewf = cg.ewr = cg.head = nullptr;        // fixed rows only: no tables
+    unsigned* rk = reinterpret_cast<unsigned*>(red + 8);
+    int st = 0;
+    for (int r = 0; r < p.rounds; ++r) {
+        int moves = 0, guard = 0;
+        while (moves < p.pm) {
+            // the tour edge of maximum utility regret / (1 + penalty), the first one among equals (:192-202)
+            double bu = -1.0;
+            unsigned bp = 0xffffffffu;
+            for (int q = tid; q < n; q += nt) {
+                const int a = t[q], b = t[q + 1];
+                const size_t e = (size_t)(a < b ? a : b) * (size_t)n + (size_t)(a < b ? b : a);
+                const double u = reg[e] / (1.0 + pen[e]);
+                if (u > bu) { bu = u; bp = (unsigned)q; }           // ascending q per lane: strict > keeps the first
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const double ou = __shfl_xor(bu, o);
+                const unsigned op_ = (unsigned)__shfl_xor((int)bp, o);
+                if (ou > bu || (ou == bu && op_ < bp)) { bu = ou; bp = op_; }
+            }
+            __syncthreads();
+            if ((tid & 63) == 0) { red[tid >> 6] = bu; rk[tid >> 6] = bp; }
+            __syncthreads();
+            bu = red[0];
+            bp = rk[0];
+            for (int w = 1; w < (nt >> 6); ++w)
+                if (red[w] > bu || (red[w] == bu && rk[w] < bp)) { bu = red[w]; bp = rk[w]; }
+            const int ea = t[bp], eb = t[bp + 1];
+            const int src = ea < eb ? ea : eb, dst = ea < eb ? eb : ea;
+            __syncthreads();
+            if (tid == 0) {                                         // :206-208
+                pen[(size_t)src * n + dst] += 1.0;
+                pen[(size_t)dst * n + src] += 1.0;
+                __threadfence();
+            }
+            __syncthreads();
+            for (int which = 0; which < 2; ++which) {               // :212-223
+                const int node = which == 0 ? src : dst;
+                if (node == 0) continue;                            // not the depot
+                for (int q = 1 + tid; q < n; q += nt)
+                    if (t[q] == node) flag[1] = q;                  // cur_tour.index(n): its one position
+                __syncthreads();
+                const int i = flag[1];
+                for (int op = 0; op < 2; ++op) {                    // the same row i for both operators
+                    double e;
+                    unsigned key;
+                    ls_best<true>(cg, op, i, tid, nt, red, e, key);
+                    if (e < 0.0) {
+                        ls_apply(t, n, op, key, tid, nt);
+                        ++moves;
+                    }
+                }
+                __syncthreads();
+            }
+            if (++guard > 100000) { st = TSP2OPT_ST_CAPPED; break; }    // the reference would spin for ever
+        }
+        gls_local_search(cp, t, tid, nt, red);                      // :226
+        const double c = gls_cost(cp, red, tid);                    // :227
+        if (c < best) {                                             // :228-229
+            best = c;
+            for (int q = tid; q <= n; q += nt) gb[q] = (int64_t)t[q];
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q <= n; q += nt) gt[q] = (int64_t)t[q];
+    if (tid == 0) {
+        p.guide_k[tk] = k;
+        p.best_cost[tk] = best;
+        if (p.status) p.status[tk] = st;
+    }
+}
+
 int ls_launch(LsParams p, int device, hipStream_t stream)
 {
     const size_t base = 144 + ((sizeof(uint16_t) * (size_t)(p.n + 1) + 15) & ~(size_t)15);
@@ -356,4 +550,38 @@ extern "C" int tsp2opt_local_search(const double* points, int64_t* tours, int32_
     p.points = points; p.tours = tours; p.rounds_out = rounds_out; p.status = status_out;
     p.num_tours = num_tours; p.n = n; p.tpi = tours_per_instance; p.op = 2; p.max_rounds = max_rounds;
     return ls_launch(p, device, static_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int tsp2opt_gls_rounds(const double* points, int64_t* tours, int64_t* best_tours, double* best_cost,
+                                  double* guide_k, double* penalty, const double* regret, int32_t* status_out,
+                                  int64_t num_tours, int32_t n, int32_t tours_per_instance, int32_t tours_per_map,
+                                  int32_t perturbation_moves, int32_t rounds, int32_t init, int32_t device,
+                                  void* hip_stream)
+{
+    int rc = ls_check(points, tours, num_tours, n, tours_per_instance);
+    if (rc) return rc;
+    if (tours_per_map < 1 || perturbation_moves < 0 || rounds < 0) return fail(TSP2OPT_E_ARG, "bad argument");
+    if (num_tours == 0) return 0;
+    if (!best_tours || !best_cost || !guide_k || !penalty || !regret) return fail(TSP2OPT_E_ARG, "null pointer");
+    if ((reinterpret_cast<uintptr_t>(best_tours) % 8) || (reinterpret_cast<uintptr_t>(best_cost) % 8) ||
+        (reinterpret_cast<uintptr_t>(guide_k) % 8) || (reinterpret_cast<uintptr_t>(penalty) % 8) ||
+        (reinterpret_cast<uintptr_t>(regret) % 8) || (reinterpret_cast<uintptr_t>(status_out) % 4))
+        return fail(TSP2OPT_E_ARG, "misaligned pointer (arrays must be aligned to their element size)");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(TSP2OPT_E_HIP, "hipSetDevice failed");
+    GlsParams p{};
+    p.points = points; p.tours = tours; p.best_tours = best_tours; p.best_cost = best_cost; p.guide_k = guide_k;
+    p.penalty = penalty; p.regret = regret; p.status = status_out; p.num_tours = num_tours; p.n = n;
+    p.tpi = tours_per_instance; p.tph = tours_per_map; p.pm = perturbation_moves; p.rounds = rounds;
+    p.init = init ? 1 : 0;
+    const size_t base = 144 + ((sizeof(uint16_t) * (size_t)(n + 1) + 15) & ~(size_t)15);
+    size_t lds = base;
+    if (base + 16 * (size_t)n <= 160 * 1024) { p.xlds = 1; lds += 16 * (size_t)n; }
+    if (p.xlds && lds + 24 * (size_t)(n + 2) <= 64 * 1024) { p.flat = 1; lds += 24 * (size_t)(n + 2); }
+    if (lds > 160 * 1024) return fail(TSP2OPT_E_UNSUPPORTED, "n too large for the local-search operators");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gls), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_gls, dim3((unsigned)num_tours), dim3(256), lds, stream, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }

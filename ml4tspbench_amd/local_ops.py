@@ -147,82 +147,78 @@ def tsp_ls(np_points, tours, adj_mat=None, device="cpu", **kwargs):
     return [r.tolist() for r in out.cpu().numpy()]
 
 
-def _tour_cost(points: np.ndarray, tour: np.ndarray):
-    # TSPEvaluator.evaluate (utils/evaluator.py:9-13): a sequential double sum in tour order
-    d = np.sqrt(np.sum(np.abs(points[tour[1:]] - points[tour[:-1]]) ** 2, axis=-1))
-    total = 0
-    for x in d:
-        total += x
-    return total
+def guided_ls_device(points: torch.Tensor, tours: torch.Tensor, heat: torch.Tensor, *, tours_per_instance: int = 1,
+                     tours_per_map: int = 1, perturbation_moves: int = 50, time_limit: float = 1.0,
+                     max_rounds: Optional[int] = None) -> torch.Tensor:
+    """(Regret) guided local search (search/local_search.py:157-232) for a whole batch, on the device.
 
+    points (I, N, 2) float64, tours (T, N+1) int64, heat (T // tours_per_map, N, N): tour k uses instance
+    k // tours_per_instance and heat map k // tours_per_map.  Every search keeps its current tour, best tour,
+    penalties and guide factor in device memory; one kernel launch runs whole outer rounds for all tours
+    (``tsp2opt_gls_rounds``).  ``max_rounds``: that many rounds in ONE launch (deterministic; tests).  Otherwise
+    the reference's wall-clock loop: one launch per round until ``time_limit`` seconds have passed (every tour
+    gets the whole limit, as in the reference, where the tours are searched one after another).
+    Returns the best tours (T, N+1) int64 on the device."""
+    if points.dim() == 2:
+        points = points.unsqueeze(0)
+    if tours.dim() == 1:
+        tours = tours.unsqueeze(0)
+    if heat.dim() == 2:
+        heat = heat.unsqueeze(0)
+    n, T = _check_batch(points, tours, int(tours_per_instance))
+    dev = points.device
+    if tours_per_map < 1 or heat.shape[0] * tours_per_map != T or tuple(heat.shape[1:]) != (n, n):
+        raise ValueError("expected heat (T / tours_per_map, N, N)")
+    adj = -1 * heat.to(device=dev, dtype=torch.float64)                # local_search.py:167
+    regret = torch.where(adj > 0, adj, torch.zeros_like(adj)).contiguous()     # :177
+    points = points.contiguous()
+    cur = tours.clone(memory_format=torch.contiguous_format)
+    best = torch.empty_like(cur)
+    best_cost = torch.empty(T, dtype=torch.float64, device=dev)
+    guide_k = torch.empty(T, dtype=torch.float64, device=dev)
+    penalty = torch.zeros((T, n, n), dtype=torch.float64, device=dev)
+    status = torch.zeros(T, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
 
-def _guided_ls_one(points: np.ndarray, tour: np.ndarray, heat: np.ndarray, dev: torch.device, time_limit: float,
-                   perturbation_moves: int, max_rounds: Optional[int]) -> np.ndarray:
-    """search/local_search.py:176-231 for one tour; move scans on the device."""
-    n = points.shape[0]
-    adj = -1 * np.asarray(heat)
-    adj = np.where(adj > 0, adj, 0)
-    d_pts = torch.from_numpy(np.ascontiguousarray(points)).to(dev)
-    init_cost = _tour_cost(points, tour)
-    k = 0.1 * init_cost / n
-    d_k = torch.tensor([k], dtype=torch.float64, device=dev)
-    d_cur, _ = local_search_device(d_pts, torch.from_numpy(tour[None]).to(dev))
-    cur = d_cur[0].cpu().numpy()
-    best, best_cost = cur.copy(), _tour_cost(points, cur)
-    pen = np.zeros((n, n))
-    d_pen = torch.zeros((1, n, n), dtype=torch.float64, device=dev)
-    t_lim = time.time() + time_limit
-    rounds = 0
-    while (time.time() < t_lim) if max_rounds is None else (rounds < max_rounds):
-        moves = 0
-        guard = 0
-        while moves < perturbation_moves:
-            src_a, dst_a = np.minimum(cur[:-1], cur[1:]), np.maximum(cur[:-1], cur[1:])
-            util = adj[src_a, dst_a] / (1 + pen[src_a, dst_a])
-            e = int(np.argmax(util))            # first edge attaining the maximum (local_search.py:189-197)
-            src, dst = int(src_a[e]), int(dst_a[e])
-            pen[src, dst] += 1.
-            pen[dst, src] += 1.
-            d_pen[0, src, dst] += 1.
-            d_pen[0, dst, src] += 1.
-            for node in (src, dst):
-                if node != 0:                   # not the depot
-                    i = int(np.nonzero(cur == node)[0][0])
-                    d_i = torch.tensor([i], dtype=torch.int32, device=dev)
-                    for op in (0, 1):
-                        d_new, delta = ls_step_device(d_pts, d_cur, op, fixed_i=d_i, guide_k=d_k, penalty=d_pen)
-                        if float(delta[0].item()) < 0:
-                            d_cur = d_new
-                            cur = d_cur[0].cpu().numpy()
-                            moves += 1
-            guard += 1
-            if guard > 100000 or (max_rounds is None and time.time() >= t_lim + 10 * max(time_limit, 1.0)):
-                break       # the reference would spin here for ever when no guided move exists
-        d_cur, _ = local_search_device(d_pts, d_cur)
-        cur = d_cur[0].cpu().numpy()
-        cur_cost = _tour_cost(points, cur)
-        if cur_cost < best_cost:
-            best, best_cost = cur.copy(), cur_cost
-        rounds += 1
+    def launch(rounds: int, init: int) -> None:
+        rc = L.tsp2opt_gls_rounds(points.data_ptr(), cur.data_ptr(), best.data_ptr(), best_cost.data_ptr(),
+                                  guide_k.data_ptr(), penalty.data_ptr(), regret.data_ptr(), status.data_ptr(), T, n,
+                                  int(tours_per_instance), int(tours_per_map), int(perturbation_moves), int(rounds),
+                                  int(init), dev.index, stream)
+        _lib.check(rc, "tsp2opt_gls_rounds")
+
+    if max_rounds is not None:
+        launch(int(max_rounds), 1)
+    else:
+        t_lim = time.time() + time_limit                                # :185 (before the first local_search here)
+        launch(0, 1)
+        torch.cuda.synchronize(dev)
+        while time.time() < t_lim:                                      # :187
+            launch(1, 0)
+            torch.cuda.synchronize(dev)
+    _raise_on_status(status)
     return best
 
 
 def tsp_gls(np_points, tours, adj_mat, device="cpu", **kwargs):
     """Drop-in for ``search/local_search.py:157-232`` (regret guided local search).  ``kwargs``:
     ``time_limit`` (seconds, per tour) and ``perturbation_moves`` like the reference; additionally
-    ``max_rounds`` replaces the wall clock by a fixed number of outer rounds (deterministic; tests)."""
+    ``max_rounds`` replaces the wall clock by a fixed number of outer rounds (deterministic; tests).
+    All tours (one per heat map of ``adj_mat``) share ``np_points`` and are searched side by side."""
     dev = _resolve_device(device)
-    pts = np.asarray(np_points, dtype=np.float64)
     adj = np.asarray(adj_mat)
     t = np.array(tours)
     if adj.ndim == 2:
         adj = adj[None]
         t = t[None] if t.ndim == 1 else t
-    out = []
-    for k in range(adj.shape[0]):
-        out.append(_guided_ls_one(pts, np.asarray(t[k], dtype=np.int64), adj[k], dev, float(kwargs.get("time_limit", 1.0)),
-                                  int(kwargs["perturbation_moves"]), kwargs.get("max_rounds")).tolist())
-    return out
+    count = adj.shape[0]
+    best = guided_ls_device(_to_dev(np.asarray(np_points, dtype=np.float64), dev, torch.float64),
+                            _to_dev(np.asarray(t[:count], dtype=np.int64), dev, torch.int64),
+                            _to_dev(adj, dev, torch.float64), tours_per_instance=count, tours_per_map=1,
+                            perturbation_moves=int(kwargs["perturbation_moves"]),
+                            time_limit=float(kwargs.get("time_limit", 1.0)), max_rounds=kwargs.get("max_rounds"))
+    return [r.tolist() for r in best.cpu().numpy()]
 
 
 class ML4TSPNARGuidedLS(ML4TSPNARLocalSearch):
@@ -236,6 +232,35 @@ class ML4TSPNARGuidedLS(ML4TSPNARLocalSearch):
     def _local_search(self, tour: np.ndarray, points: np.ndarray, heatmap: np.ndarray = None) -> np.ndarray:
         self.nodes_num = points.shape[-2]
         dev = _resolve_device(self.device)
-        return _guided_ls_one(np.asarray(points, dtype=np.float64), np.asarray(tour, dtype=np.int64),
-                              np.asarray(heatmap), dev, float(self.time_limit), int(self.perturbation_moves),
-                              self.max_rounds)
+        best = guided_ls_device(_to_dev(np.asarray(points, dtype=np.float64), dev, torch.float64),
+                                _to_dev(np.asarray(tour, dtype=np.int64), dev, torch.int64),
+                                _to_dev(np.asarray(heatmap), dev, torch.float64),
+                                perturbation_moves=int(self.perturbation_moves), time_limit=float(self.time_limit),
+                                max_rounds=self.max_rounds)
+        return best[0].cpu().numpy()
+
+    def local_search(self, tours, points, heatmap=None, per_tours_num: int = 1, per_heatmap_num: int = 1):
+        """The base class's per-tour loop (base.py:58-64) as ONE batched device search: tour idx uses
+        points[idx // per_tours_num // per_heatmap_num] and heatmap[idx // per_tours_num]."""
+        if heatmap is None:
+            raise ValueError("guided local search needs the heat map")
+        from .local_search import to_numpy
+        self.tours, self.points, self.heatmap = to_numpy(tours), to_numpy(points), to_numpy(heatmap)
+        self.check_tours_dim()
+        self.check_points_dim()
+        self.check_heatmap_dim()
+        tours, points, heatmap = self.tours, self.points, self.heatmap
+        self.nodes_num = points.shape[-2]
+        dev = _resolve_device(self.device)
+        T = tours.shape[0]
+        if (T != points.shape[0] * per_tours_num * per_heatmap_num or T != heatmap.shape[0] * per_tours_num):
+            return super().local_search(tours, points, heatmap, per_tours_num, per_heatmap_num)
+        best = guided_ls_device(_to_dev(np.asarray(points, dtype=np.float64), dev, torch.float64),
+                                _to_dev(np.asarray(tours, dtype=np.int64), dev, torch.int64),
+                                _to_dev(np.asarray(heatmap), dev, torch.float64),
+                                tours_per_instance=per_tours_num * per_heatmap_num, tours_per_map=per_tours_num,
+                                perturbation_moves=int(self.perturbation_moves), time_limit=float(self.time_limit),
+                                max_rounds=self.max_rounds)
+        out = best.cpu().numpy()
+        self._validate(out)
+        return out

@@ -189,6 +189,43 @@ def test_gpu_guided_local_search_matches_reference():
 
 
 @pytest.mark.gpu
+def test_gpu_batched_guided_local_search_matches_oracle(lso):
+    """guided_ls_device: all tours of a batch side by side, whole rounds in one launch (tsp2opt_gls_rounds),
+    against the oracle's per-tour driver; the same rounds split over several launches (state kept in device
+    memory between calls); the plugin's batched local_search with its instance / heat-map mapping."""
+    import ml4tspbench_amd as amd
+    rng = np.random.default_rng(77)
+    for n, inst, per, rounds, pm in ((12, 3, 2, 3, 4), (40, 2, 3, 2, 10), (90, 2, 1, 2, 15)):
+        pts = rng.random((inst, n, 2))
+        T = inst * per
+        tours = np.zeros((T, n + 1), dtype=np.int64)
+        for k in range(T):
+            tours[k, 1:n] = rng.permutation(np.arange(1, n))
+        d = np.linalg.norm(pts[:, :, None] - pts[:, None], axis=-1)
+        heat = -np.exp(-np.repeat(d, per, axis=0) / (0.35 / np.sqrt(n))) * (0.6 + 0.8 * rng.random((T, n, n)))
+        heat[0, :, 3] = 0.5                              # positive heat: regret 0 after the clamp
+        ref = np.array([lso.guided_local_search(pts[k // per], tours[k], heat[k], rounds=rounds,
+                                                perturbation_moves=pm) for k in range(T)])
+        got = amd.guided_ls_device(_dev(pts, torch.float64), _dev(tours, torch.int64), _dev(heat, torch.float64),
+                                   tours_per_instance=per, tours_per_map=1, perturbation_moves=pm, max_rounds=rounds)
+        assert np.array_equal(got.cpu().numpy(), ref), n
+        plug = amd.ML4TSPNARGuidedLS(perturbation_moves=pm, max_rounds=rounds)
+        out = plug.local_search(tours, pts, heat, per_tours_num=1, per_heatmap_num=per)
+        assert np.array_equal(out, ref), n
+    # one heat map shared by two tours (per_tours_num = 2)
+    n, pm = 30, 6
+    pts = rng.random((2, n, 2))
+    tours = np.zeros((4, n + 1), dtype=np.int64)
+    for k in range(4):
+        tours[k, 1:n] = rng.permutation(np.arange(1, n))
+    heat = -rng.random((2, n, n))
+    ref = np.array([lso.guided_local_search(pts[k // 2], tours[k], heat[k // 2], rounds=2, perturbation_moves=pm)
+                    for k in range(4)])
+    out = amd.ML4TSPNARGuidedLS(perturbation_moves=pm, max_rounds=2).local_search(tours, pts, heat, per_tours_num=2)
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.gpu
 def test_gpu_ls_rejects_bad_tours():
     import ml4tspbench_amd as amd
     pts = np.random.default_rng(0).random((1, 9, 2))

@@ -44,3 +44,30 @@ print(json.dumps({
     "matches_oracle_on_sample": bool(np.array_equal(out[:k].cpu().numpy(), ref)
                                      and np.array_equal(rounds[:k].cpu().numpy(), ref_rounds)),
 }))
+
+# ---- guided local search (search/local_search.py:157-232): whole rounds on the device, all tours side by side
+gn, gt_, grounds, gpm = a.n, min(256, a.tours), 5, 20
+rng = np.random.default_rng(4321)
+gp = rng.random((gt_, gn, 2))
+gtours = np.zeros((gt_, gn + 1), dtype=np.int64)
+for k in range(gt_):
+    gtours[k, 1:gn] = rng.permutation(np.arange(1, gn))
+d = np.linalg.norm(gp[:, :, None] - gp[:, None], axis=-1)
+gheat = -np.exp(-d / (0.35 / np.sqrt(gn))) * (0.6 + 0.8 * rng.random((gt_, gn, gn)))     # regrets = -heat > 0
+g_p, g_t, g_h = torch.from_numpy(gp).to(dev), torch.from_numpy(gtours).to(dev), torch.from_numpy(gheat).to(dev)
+amd.guided_ls_device(g_p, g_t, g_h, perturbation_moves=gpm, max_rounds=1); torch.cuda.synchronize()
+t0 = time.perf_counter()
+gbest = amd.guided_ls_device(g_p, g_t, g_h, perturbation_moves=gpm, max_rounds=grounds)
+torch.cuda.synchronize()
+g_s = time.perf_counter() - t0
+kk = min(8, gt_)
+t0 = time.perf_counter()
+gref = [ls_oracle.guided_local_search(gp[k], gtours[k], gheat[k], rounds=grounds, perturbation_moves=gpm) for k in range(kk)]
+gcpu_s = time.perf_counter() - t0
+print(json.dumps({
+    "op": "guided local search (tsp_gls), whole rounds on the device", "nodes": gn, "tours": gt_, "rounds": grounds,
+    "perturbation_moves": gpm, "gpu_ms": g_s * 1e3, "gpu_rounds_per_s": gt_ * grounds / g_s,
+    "cpu_oracle": {"tours": kk, "s": gcpu_s, "rounds_per_s": kk * grounds / gcpu_s, "threads": 1,
+                   "note": "oracle/ls_oracle.py: the C operators driven by a Python loop like the reference's"},
+    "matches_oracle_on_sample": bool(all(np.array_equal(gbest[k].cpu().numpy(), gref[k]) for k in range(kk))),
+}))
