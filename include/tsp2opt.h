@@ -315,7 +315,8 @@ int tsp2opt_debug_cluster_inc(int32_t on);
  * one-workgroup kernel's request (lowers the workgroups resident per CU: occupancy sweeps; default 0);
  * what = 6: 1 replays coupled calls (group_size > 1) entirely in the lock-step kernel (tests; default 0);
  * what = 7: band cluster kernel, log2 of the macro steps per part when a listed cache group is recomputed
- * (default 3).  The knobs belong to the calling thread. */
+ * (default 3); what = 8: 0 plans small tours without the tile cache in whole tiles per lane instead of macro-step
+ * units (default 1).  The knobs belong to the calling thread. */
 int tsp2opt_debug_tune(int32_t what, int32_t value);
 /* Geometry the library would pick for `num_tours` tours of n nodes on a device with `cus` compute
  * units when several workgroups share a tour (host-only, for logs and tests):

@@ -103,6 +103,7 @@ struct Opts {
     int cluster_variant = 0;    // 0 auto, 1 band kernel only (k_two_opt_cluster), 2 full-window kernel only
     int force_lockstep = 0;     // coupled mode: replay the whole call in k_group_lockstep (tests)
     int part_sh = 3;            // band cluster: listed groups are recomputed in parts of at most 2^part_sh macro steps
+    int half_units = 1;         // macro-step units for small tours without the tile cache (Geo::half)
 };
 thread_local Opts t_opts;
 
@@ -293,6 +294,23 @@ Plan make_plan_nt(const Opts& o, int n, int dtype, int cs, int nt_cap)
                     cache = need;
                 }
             }
+        }
+    }
+    // Small tours without the cache (one or two tiles per lane): units of whole tiles leave lanes idle and round the
+    // work per lane up to the next even number of macro steps (TSP-100: 49 of 64 lanes with 4 steps each for 175
+    // steps of work, TSP-50: 21 lanes with 2).  Macro-step units (Geo::half) start at any macro row: 63 lanes with
+    // 3 steps, 39 lanes with 1.
+    if (g.qclass && !g.inc && cs == 1 && o.half_units) {
+        const int R = (n + 3) / 4;
+        int NS = nt / g.GPl;
+        if (NS < 1) NS = 1;
+        if (NS > R) NS = R;
+        const int MS = (R + NS - 1) / NS;
+        NS = (R + MS - 1) / MS;
+        const int W = (4 * NS * MS + 8 * g.GP + 8 + 7) & ~7;
+        if (MS < g.MS && MS <= 16 && R <= 255 && W / 8 + 1 <= g.qclass && W < 3 * n) {
+            g.half = 1; g.NS = NS; g.MS = MS; g.W = W;
+            pl.S = 4 * MS; pl.W = W;
         }
     }
     pl.lds = base + (size_t)g.qclass * 192 + cache;
@@ -985,6 +1003,7 @@ extern "C" int tsp2opt_debug_tune(int32_t what, int32_t value)
     else if (what == 5) o.lds_pad = value < 0 ? 0 : value;
     else if (what == 6) o.force_lockstep = value ? 1 : 0;
     else if (what == 7) o.part_sh = value < 0 ? 0 : value > 6 ? 6 : value;
+    else if (what == 8) o.half_units = value ? 1 : 0;
     else return fail(TSP2OPT_E_ARG, "unknown tuning knob");
     return 0;
 }

@@ -28,6 +28,8 @@ struct Geo {                          // launch geometry of the filter sweep (ho
     int xlds;                         // exact coordinates cached in LDS
     int W;                            // window entries kept consistent (multiple of 8, <= 8*Q)
     int inc;                          // tile-minimum cache + incremental sweeps
+    int half;                         // small tours without the cache: the lane unit is MS macro steps starting at ANY
+                                      // macro row (MS may be odd), chunks are macro steps (4 rows x 8 diagonals)
     int lcap;                         // capacity of the changed-tile list
     float eps2;                       // 2*eps of the filter, in scaled units
     float inv_gpl;                    // 1 / GPl: unit -> (row segment, lane group) without an integer division

@@ -83,6 +83,61 @@ __device__ __forceinline__ float macro_step(const v2f* Xq, const v2f* Yq, const 
     return mm;
 }
 
+// The same with the row parity of the macro step in a register (Geo::half: units start at any macro row, so the
+// lanes of a wave differ in parity).  Window position w sits in sub-array w & 7 at index w >> 3: moving 4
+// positions on (par = 1) moves sub-arrays 0..3 to 4..7 (+4Q entries: oa) and 4..7 to 0..3 of the next index
+// (+1 - 4Q entries: ob), so every operand keeps a compile-time offset from one of two lane bases.
+template <int Q>
+__device__ __forceinline__ void load_block_rt(const v2f* Xq, const v2f* Yq, const v2f* Eq, int b, int par,
+                                              v2f (&CX)[4], v2f (&CY)[4], v2f (&E)[4])
+{
+    const int oa = b + par * (4 * Q), ob = b + par * (1 - 4 * Q);
+    CX[0] = Xq[2 * Q + oa]; CX[1] = Xq[3 * Q + oa]; CX[2] = Xq[4 * Q + ob]; CX[3] = Xq[5 * Q + ob];
+    CY[0] = Yq[2 * Q + oa]; CY[1] = Yq[3 * Q + oa]; CY[2] = Yq[4 * Q + ob]; CY[3] = Yq[5 * Q + ob];
+    E[0] = Eq[Q + oa]; E[1] = Eq[2 * Q + oa]; E[2] = Eq[3 * Q + oa]; E[3] = Eq[4 * Q + ob];
+}
+
+template <int Q>
+__device__ __forceinline__ float macro_step_rt(const v2f* Xq, const v2f* Yq, const v2f* Eq,
+                                               int rq, int cb, int par,
+                                               const v2f (&CXo)[4], const v2f (&CYo)[4], v2f (&CXn)[4],
+                                               v2f (&CYn)[4], const v2f (&Eo)[4], v2f (&En)[4],
+                                               v2f (&Dc)[4])
+{
+    load_block_rt<Q>(Xq, Yq, Eq, cb + par, 1 - par, CXn, CYn, En);
+    const int oa = rq + par * (4 * Q), ob = rq + par * (1 - 4 * Q);
+    float rx[4], ry[4], er[4];
+    rx[0] = Xq[Q + oa].x;     ry[0] = Yq[Q + oa].x;             // P[r0+1], r0 = 8 rq + 4 par
+    rx[1] = Xq[2 * Q + oa].x; ry[1] = Yq[2 * Q + oa].x;
+    rx[2] = Xq[3 * Q + oa].x; ry[2] = Yq[3 * Q + oa].x;
+    rx[3] = Xq[4 * Q + ob].x; ry[3] = Yq[4 * Q + ob].x;         // P[r0+4]
+    er[0] = Eq[oa].x;                                           // e[r0]
+    er[1] = Eq[Q + oa].x;
+    er[2] = Eq[2 * Q + oa].x;
+    er[3] = Eq[3 * Q + oa].x;
+    float mm = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        v2f t[4], Dn[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int vp = a + q + 1;
+            Dn[q] = dist32x2(rx[a], ry[a], vp < 4 ? CXo[vp] : CXn[vp - 4],
+                             vp < 4 ? CYo[vp] : CYn[vp - 4]);
+            const int ve = a + q;
+            t[q] = (Dc[q] + Dn[q]) - (ve < 3 ? Eo[ve + 1] : En[ve - 3]);
+        }
+        float m = __builtin_fminf(__builtin_fminf(t[0].x, t[0].y), t[1].x);
+        m = __builtin_fminf(__builtin_fminf(m, t[1].y), t[2].x);
+        m = __builtin_fminf(__builtin_fminf(m, t[2].y), t[3].x);
+        m = __builtin_fminf(m, t[3].y) - er[a];
+        mm = __builtin_fminf(mm, m);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Dc[q] = Dn[q];
+    }
+    return mm;
+}
+
 __device__ __forceinline__ void track(float mm, unsigned id, float& a1, float& a2, unsigned& chunk)
 {
     a2 = __builtin_amdgcn_fmed3f(a1, mm, a2);   // runner-up (a1 <= a2 invariant)
@@ -103,6 +158,35 @@ __device__ __forceinline__ void filter_sweep(const v2f* Xq, const v2f* Yq, const
     a2 = INFINITY;
     chunk = 0;
     const int units = g.GPl * g.NS, MS2 = g.MS >> 1;
+    if constexpr (!CL) {
+        if (g.half) {       // (uniform) macro-step units: chunk id = (macro row << 8) | lane group
+            for (int u = tid; u < units; u += g.nt) {
+                const int s = div_gpl(g, u), gpl = u - s * g.GPl;
+                const int m0 = s * g.MS;
+                int par = m0 & 1, rq = m0 >> 1, cb = rq + gpl;
+                v2f CX0[4], CY0[4], CX1[4], CY1[4], E0[4], E1[4], Dc[4];
+                load_block_rt<Q>(Xq, Yq, Eq, cb, par, CX0, CY0, E0);
+                const float ax = Xq[rq + par * (4 * Q)].x, ay = Yq[rq + par * (4 * Q)].x;      // P[r0]
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Dc[q] = dist32x2(ax, ay, CX0[q], CY0[q]);
+                unsigned id = ((unsigned)m0 << 8) | (unsigned)gpl;
+                int k = 0;
+                for (; k + 1 < g.MS; k += 2) {
+                    float mm = macro_step_rt<Q>(Xq, Yq, Eq, rq, cb, par, CX0, CY0, CX1, CY1, E0, E1, Dc);
+                    track(mm, id, a1, a2, chunk);
+                    id += 256u; rq += par; cb += par; par ^= 1;
+                    mm = macro_step_rt<Q>(Xq, Yq, Eq, rq, cb, par, CX1, CY1, CX0, CY0, E1, E0, Dc);
+                    track(mm, id, a1, a2, chunk);
+                    id += 256u; rq += par; cb += par; par ^= 1;
+                }
+                if (k < g.MS) {
+                    const float mm = macro_step_rt<Q>(Xq, Yq, Eq, rq, cb, par, CX0, CY0, CX1, CY1, E0, E1, Dc);
+                    track(mm, id, a1, a2, chunk);
+                }
+            }
+            return;
+        }
+    }
     for (int u = tid; u < units; u += g.nt) {
         const int s = div_gpl(g, u), gpl = u - s * g.GPl;
         const int gp = CL ? g.wc + g.CS * gpl : gpl;
@@ -358,9 +442,11 @@ __device__ __forceinline__ int wrap3(int w, int n)
 }
 
 // window positions (row, column) of pair `pr` (0..63: row 0..7, diagonal 0..7) of tile `id`
+// (Geo::half: the chunk is a macro step, id >> 8 its macro row: pairs 0..31; pairs 32..63 are the next macro
+//  step's, valid pairs of the window too, which the callers leave out)
 __device__ __forceinline__ void tile_pair(const Geo& g, unsigned id, int pr, int& rw, int& cw)
 {
-    rw = 8 * (int)(id >> 8) + (pr >> 3);
+    rw = (g.half ? 4 : 8) * (int)(id >> 8) + (pr >> 3);
     cw = rw + 2 + 8 * (g.wc + g.CS * (int)(id & 255u)) + (pr & 7);
 }
 
@@ -498,6 +584,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
                     float d;
                     unsigned di;
                     filter_chunk_pair<Q>(v, g, id, lane, d, di);
+                    if (g.half && lane >= 32) d = INFINITY;         // a macro step has 32 pairs
                     if (d <= thr) {
                         multi = multi || (fidx != 0xffffffffu && fidx != di);
                         if (d < fd || (d == fd && di < fidx)) { fd = d; fidx = di; }
@@ -579,7 +666,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
                 double d;
                 unsigned di;
                 eval_chunk_pair(v, g, id, lane, d, di);
-                if (better(d, di, e, idx)) { e = d; idx = di; }
+                if (!(g.half && lane >= 32) && better(d, di, e, idx)) { e = d; idx = di; }
             }
             if (tid == 0) {
                 const double d = exact_delta(v, g.n, 0, g.n - 1);
