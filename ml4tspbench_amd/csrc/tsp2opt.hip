@@ -93,6 +93,7 @@ struct Opts {
     int dbg_sweeps = 0;         // filter sweeps only (tsp2opt_debug_sweep_only)
     int stamps = 0;             // phase timers into workspace bytes [64, 256)
     int force_nt = 0;           // threads per workgroup of the single-workgroup plan
+    int wide_few = 1;           // twice the threads per tour when the batch has at most one tour per CU
     int lcap16 = 13;            // changed-group list capacity of the band cluster kernel, in 1/16 of the groups
     int lcap16s = 13;           // changed-tile list capacity of the one-workgroup / full-window kernel, in 1/16 of the tiles
     int lds_pad = 0;            // unused LDS bytes added to the one-workgroup kernel's request (occupancy sweeps)
@@ -599,7 +600,19 @@ int solve_t(const Opts& o, const void* points, int64_t* tours, int32_t* iters_ou
             int group_size, int max_iter, double time_limit_s, int dtype, int device, void* ws,
             hipStream_t stream)
 {
-    const Plan pl = make_plan(o, n, dtype);
+    Plan pl = make_plan(o, n, dtype);
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    // A batch that leaves every workgroup a CU to itself: twice the threads per tour (twice the row segments, half
+    // the tiles per unit).  The listed tiles of an iteration then take half as many passes, and a lone workgroup's
+    // iteration is a latency chain, not an issue-rate problem; with two or more workgroups per CU the narrower
+    // geometry wins (measured: N = 200..640 at 128..256 tours 7..15 % faster, at 384 tours even or slower).
+    if (o.wide_few && !o.force_nt && pl.g.inc && num_tours <= cus && (pl.g.nt == 128 || pl.g.nt == 256)) {
+        Opts o2 = o;
+        o2.force_nt = 2 * pl.g.nt;
+        const Plan p2 = make_plan(o2, n, dtype);
+        if (p2.g.inc && p2.g.nt == 2 * pl.g.nt) pl = p2;
+    }
     const WsLayout wl = ws_layout(num_tours, group_size);
     unsigned char* w8 = static_cast<unsigned char*>(ws);
     Params p{};
@@ -641,8 +654,6 @@ int solve_t(const Opts& o, const void* points, int64_t* tours, int32_t* iters_ou
     ClusterChoice cc{};
     cc.kind = 0;
     if (group_size == 1 && o.cluster_mode != 0 && o.dbg_sweeps == 0) {
-        int cus = 0;
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
         cc = choose_cluster(o, n, dtype, num_tours, cus, pl);
         if (cc.kind != 0) HIP_TRY(hipMemsetAsync(w8 + wl.off_csync, 0, kCsyncBytes, stream));
         if (cc.kind == 1) {
@@ -1004,6 +1015,7 @@ extern "C" int tsp2opt_debug_tune(int32_t what, int32_t value)
     else if (what == 6) o.force_lockstep = value ? 1 : 0;
     else if (what == 7) o.part_sh = value < 0 ? 0 : value > 6 ? 6 : value;
     else if (what == 8) o.half_units = value ? 1 : 0;
+    else if (what == 9) o.wide_few = value ? 1 : 0;
     else return fail(TSP2OPT_E_ARG, "unknown tuning knob");
     return 0;
 }

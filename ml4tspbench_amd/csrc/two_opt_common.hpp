@@ -93,10 +93,20 @@ __device__ __forceinline__ Prof make_prof(const unsigned long long* stamps)
 
 // Diagnostic build only (-DTSP2OPT_FINE, libtsp2opt_hip_fine.so): FINE(pf, k) charges the shader-clock
 // cycles since the previous mark to slot k; the slots are summed into workspace stamps [8, 24).
+// TSP2OPT_FINE_MASK (default: everything) keeps only the marks whose slot bit is set -- a clock read costs a few
+// hundred cycles of a latency chain, so a phase is best measured with only its own marks compiled in; bit 15 = the
+// coarse sweep / select / apply timers.  FINE_START_G(pf, slots) starts the clock if any of `slots` is kept.
+#ifndef TSP2OPT_FINE_MASK
+#define TSP2OPT_FINE_MASK 0xffff
+#endif
 #ifdef TSP2OPT_FINE
-#define FINE_START(pf) do { if ((pf).on) (pf).tl = clock64(); } while (0)
-#define FINE(pf, k) do { if ((pf).on) { const unsigned long long t_ = clock64(); (pf).fine[k] += t_ - (pf).tl; (pf).tl = t_; } } while (0)
+#define FINE_START_G(pf, slots) do { if (((TSP2OPT_FINE_MASK) & (slots)) && (pf).on) (pf).tl = clock64(); } while (0)
+#define FINE_START(pf) FINE_START_G(pf, 0xffff)
+#define FINE(pf, k) do { if ((((TSP2OPT_FINE_MASK) >> (k)) & 1) && (pf).on) { const unsigned long long t_ = clock64(); (pf).fine[k] += t_ - (pf).tl; (pf).tl = t_; } } while (0)
+#define COARSE(pf) ((((TSP2OPT_FINE_MASK) >> 15) & 1) && (pf).on)
 #else
+#define FINE_START_G(pf, slots) do { } while (0)
+#define COARSE(pf) ((pf).on)
 #define FINE_START(pf) do { } while (0)
 #define FINE(pf, k) do { } while (0)
 #endif

@@ -402,7 +402,7 @@ template <int Q, bool CL, typename T>
 __device__ __forceinline__ void refresh_cached(const View<T>& v, const Geo& g, int tid, unsigned last, Prof& pf)
 {
     Ctl* ctl = v.ctl;
-    FINE_START(pf);
+    FINE_START_G(pf, 0x000e);
     const unsigned nl = ctl->nlist;
     __builtin_amdgcn_s_setprio(0);
     if (last == kFullSweep || nl > (unsigned)g.lcap) {      // (uniform) first sweep, or most of the tour moved
@@ -806,7 +806,7 @@ __device__ void select_cached(const View<T>& v, const Geo& g, int tid, bool need
     int code = 0;                                       // 0: (e, idx) final, 1: exact stage, 2: heavy ties
     e = 0.0;
     idx = kNoMove;
-    FINE_START(pf);
+    FINE_START_G(pf, 0x02f0);
     if (mine) {
         const UnitMinima um = load_unit_minima(v, g, lane);     // one LDS round trip together with sc / spd
         const double scale = ctl->sc, iscale = ctl->isc;
@@ -839,6 +839,70 @@ __device__ void select_cached(const View<T>& v, const Geo& g, int tid, bool need
             // window it IS the reference's argmin, and if its value is below -1e-6 by more than eps the move
             // is certain without any exact arithmetic.  Likewise a window that lies above -1e-6 + eps proves
             // convergence.  Anything else goes to the exact stage.
+            //
+            // Fast path, straight-line (the usual case once the tour is nearly converged, where this serial
+            // chain of one wave IS the iteration's critical path): exactly one unit, one tile of it and one
+            // pair of that tile inside the window.  Same decision as the general code below for that case.
+            bool fast = false;
+#ifndef TSP2OPT_NO_FASTC
+            {
+                const unsigned kthr = fkey(thr);
+                // (ballots: one compare per key and scalar bookkeeping instead of per-lane counters)
+                int c1 = 0, u = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c < um.nch) {                                   // (uniform)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned key = k == 0 ? um.k[c].x : k == 1 ? um.k[c].y : k == 2 ? um.k[c].z : um.k[c].w;
+                            const unsigned long long b = __ballot(key <= kthr);
+                            c1 += __popcll(b);
+                            if (b) u = 256 * c + 4 * (__ffsll((long long)b) - 1) + k;
+                        }
+                    }
+                }
+                {
+                    if (c1 == 1) {
+                        const int MS2 = g.MS >> 1;
+                        const int s = div_gpl(g, u), gpl = u - s * g.GPl;
+                        const int rq0 = s * MS2;
+                        const unsigned cm = v.Mc[(rq0 + (lane < MS2 ? lane : MS2 - 1)) * g.GPl + gpl];
+                        const unsigned long long tb = __ballot(lane < MS2 && cm <= kthr);
+                        if (__popcll(tb) == 1) {
+                            const int m2 = __ffsll((long long)tb) - 1;
+                            float d;
+                            unsigned di;
+                            filter_chunk_pair_b<Q>(v, g, ((unsigned)(rq0 + m2) << 8) | (unsigned)gpl, lane, d, di);
+                            const bool sp = spd <= thr;                 // the pair (0, n-1), (uniform)
+                            const unsigned long long wb = __ballot(d <= thr);
+                            if (__popcll(wb) + (sp ? 1 : 0) == 1) {
+                                FINE(pf, 5);
+                                float wd = spd;
+                                unsigned widx = (unsigned)(g.n - 1);
+                                if (!sp) {
+                                    const int wl = __ffsll((long long)wb) - 1;
+                                    wd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), wl));
+                                    widx = (unsigned)__builtin_amdgcn_readlane((int)di, wl);
+                                }
+                                code = 1;
+                                if (wd < -thr_scale - eps) {                            // certain improving move
+                                    e = ((double)wd + (double)eps) * iscale;
+                                    idx = widx;
+                                    code = 0;
+                                } else if (!need_exact_sign && m > -thr_scale + eps && wd > -thr_scale + eps) {
+                                    e = 0.0;
+                                    idx = kNoMove;
+                                    code = 0;
+                                }
+                                FINE(pf, 6);
+                                fast = true;
+                            }
+                        }
+                    }
+                }
+            }
+#endif
+            if (!fast) {
             float fd = INFINITY;
             unsigned fidx = 0xffffffffu;
             bool multi = false;
@@ -881,6 +945,7 @@ __device__ void select_cached(const View<T>& v, const Geo& g, int tid, bool need
                 }
                 FINE(pf, 6);
             }
+            }   // !fast
         }
     }
     if constexpr (!CL) {
@@ -1058,7 +1123,7 @@ template <typename T, int Q>
 __device__ __forceinline__ void apply_move(const View<T>& v, const Geo& g, int tid, int lo0, int len, Prof& pf)
 {
     const int n = g.n;
-    FINE_START(pf);
+    FINE_START_G(pf, 0x0100);
     const int h = len >> 1;                     // position swaps
     const int he = (len - 1) >> 1;              // the interior edges are mirrored (he <= h)
     for (int k = tid; k < h; k += g.nt) {
@@ -1442,14 +1507,14 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
             if constexpr (Q != 0) {
                 if (cached) {
                     unsigned long long t0 = 0;
-                    if (pf.on) t0 = clock64();
+                    if (COARSE(pf)) t0 = clock64();
                     refresh_cached<Q, CL>(v, g, tid, last, pf);                 // phase B
                     __syncthreads();
                     FINE(pf, 2);                                                // barrier after the refresh
                     if (tid == 0) ctl->nlist = 0;
-                    if (pf.on) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
+                    if (COARSE(pf)) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
                     select_cached<T, Q, CL>(v, g, tid, forced, sweeps, e, idx, pf);    // phase C
-                    if (pf.on) pf.select += clock64() - t0;
+                    if (COARSE(pf)) pf.select += clock64() - t0;
                 }
             }
             if (!cached) find_best<T, Q, CL>(v, g, tid, forced, last, e, idx, pf);
@@ -1482,10 +1547,10 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
                 have_prev = true; prev_idx = idx; prev_active = active;
             }
             unsigned long long ta = 0;
-            if (pf.on) ta = clock64();
+            if (COARSE(pf)) ta = clock64();
             // (cached path: select_cached / the cluster exchange ended with the barrier after which nobody
             //  reads the window any more)
-            FINE_START(pf);
+            FINE_START_G(pf, 0x0501);
             int lo0, len;
             resolve_move<Q>(v, n, idx, lo0, len);               // which side of the cycle; frame update
             apply_move<T, Q>(v, g, tid, lo0, len, pf);          // phase A
@@ -1496,7 +1561,7 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
             __syncthreads();
             FINE(pf, 10);                                       // closing barrier
             last = idx;
-            if (pf.on) pf.apply += clock64() - ta;
+            if (COARSE(pf)) pf.apply += clock64() - ta;
             if (stop_after) break;
             ++it;
             if (!forced) {

@@ -68,6 +68,7 @@ try:
         mode = {"auto": -1, "one_wg": 0, "cluster2": 2, "cluster4": 4, "lockstep": -1}[str(variant)]
         L.tsp2opt_debug_cluster_mode(mode)
         L.tsp2opt_debug_tune(6, 1 if (variant == "lockstep" and grouped) else 0)
+        L.tsp2opt_debug_tune(9, int(rng.random() < 0.5))       # small batches: wide geometry or that of large batches
         res = amd.two_opt_device(torch.from_numpy(pts).to(dev), torch.from_numpy(tours).to(dev), tours_per_instance=tpi,
                                  group_size=group, max_iterations=cap, want_lengths=False)
         got_t, got_i, got_s = res.tours.cpu().numpy(), res.iterations.cpu().numpy(), res.sweeps.cpu().numpy()
@@ -88,5 +89,6 @@ try:
 finally:
     L.tsp2opt_debug_cluster_mode(-1)
     L.tsp2opt_debug_tune(6, 0)
+    L.tsp2opt_debug_tune(9, 1)
 print(json.dumps({"cases": cases, "mismatches": fails, "seed": a.seed, "by_variant": stats}))
 sys.exit(1 if fails else 0)

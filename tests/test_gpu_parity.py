@@ -309,13 +309,17 @@ def test_gpu_profile_history(amd):
         L.tsp2opt_profile_enable(0)
 
 
-@pytest.mark.parametrize("lo,hi,step,force", [(4, 200, 1, 0), (201, 700, 13, 0), (18, 330, 8, 3)])
-def test_gpu_every_n_matches_oracle(amd, oracle, lo, hi, step, force):
+@pytest.mark.parametrize("lo,hi,step,force,wide", [(4, 200, 1, 0, 1), (201, 700, 13, 0, 1), (18, 330, 8, 3, 1),
+                                                   (161, 660, 7, 0, 0)])
+def test_gpu_every_n_matches_oracle(amd, oracle, lo, hi, step, force, wide):
     """Geometry boundaries (threads per workgroup, filter class, tile cache on/off, cluster split):
-    a grid of N through the automatic kernel choice and through forced clusters, both dtypes."""
+    a grid of N through the automatic kernel choice and through forced clusters, both dtypes.  wide = 0: the
+    geometry of large batches (tsp2opt_debug_tune(9, 0): a batch of at most one tour per CU otherwise gets twice
+    the threads per tour, and these three-tour batches would never run the geometry the benchmarks run)."""
     from ml4tspbench_amd import _lib
     L = _lib.lib()
     L.tsp2opt_debug_cluster_mode(force if force else -1)
+    L.tsp2opt_debug_tune(9, wide)
     bad = []
     try:
         for n in range(lo, hi + 1, step):
@@ -329,6 +333,7 @@ def test_gpu_every_n_matches_oracle(amd, oracle, lo, hi, step, force):
                     bad.append((n, dtype.__name__))
     finally:
         L.tsp2opt_debug_cluster_mode(-1)
+        L.tsp2opt_debug_tune(9, 1)
     assert not bad, bad
 
 
@@ -463,4 +468,5 @@ def test_gpu_single_workgroup_geometry_boundaries(amd, oracle):
                     bad.append((n, dtype.__name__))
     finally:
         L.tsp2opt_debug_cluster_mode(-1)
+        L.tsp2opt_debug_tune(9, 1)
     assert not bad, bad
