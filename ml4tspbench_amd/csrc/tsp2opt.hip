@@ -94,6 +94,7 @@ struct Opts {
     int stamps = 0;             // phase timers into workspace bytes [64, 256)
     int force_nt = 0;           // threads per workgroup of the single-workgroup plan
     int wide_few = 1;           // twice the threads per tour when the batch has at most one tour per CU
+    int extra_waves = 4;        // ... plus this many waves without a unit (they apply the reversal while the others mark)
     int lcap16 = 13;            // changed-group list capacity of the band cluster kernel, in 1/16 of the groups
     int lcap16s = 13;           // changed-tile list capacity of the one-workgroup / full-window kernel, in 1/16 of the tiles
     int lds_pad = 0;            // unused LDS bytes added to the one-workgroup kernel's request (occupancy sweeps)
@@ -604,14 +605,23 @@ int solve_t(const Opts& o, const void* points, int64_t* tours, int32_t* iters_ou
     int cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
     // A batch that leaves every workgroup a CU to itself: twice the threads per tour (twice the row segments, half
-    // the tiles per unit).  The listed tiles of an iteration then take half as many passes, and a lone workgroup's
-    // iteration is a latency chain, not an issue-rate problem; with two or more workgroups per CU the narrower
-    // geometry wins (measured: N = 200..640 at 128..256 tours 7..15 % faster, at 384 tours even or slower).
-    if (o.wide_few && !o.force_nt && pl.g.inc && num_tours <= cus && (pl.g.nt == 128 || pl.g.nt == 256)) {
+    // the tiles per unit; four times for N = 130..160).  The listed tiles of an iteration then take half as many
+    // passes, and a lone workgroup's iteration is a latency chain, not an issue-rate problem; with two or more
+    // workgroups per CU the narrower geometry wins (measured: N = 100..640 at 128..256 tours 7..28 % faster, at 384
+    // tours even or slower, N = 50 slower).
+    const int widen = pl.g.nt == 64 ? (n >= 130 ? 4 : n >= 96 ? 2 : 1) : (pl.g.nt == 128 || pl.g.nt == 256) ? 2 : 1;
+    if (o.wide_few && !o.force_nt && pl.g.qclass && num_tours <= cus && widen > 1) {
         Opts o2 = o;
-        o2.force_nt = 2 * pl.g.nt;
+        o2.force_nt = widen * pl.g.nt;
         const Plan p2 = make_plan(o2, n, dtype);
-        if (p2.g.inc && p2.g.nt == 2 * pl.g.nt) pl = p2;
+        if (p2.g.qclass && p2.g.nt == widen * pl.g.nt) {
+            pl = p2;
+            if (pl.g.inc) {     // ... and waves without a unit: they apply the reversal while the others mark
+                const int cap = pl.g.qclass == 256 ? 512 : 1024;    // kMaxThreads of the filter class
+                pl.g.u0 = std::min(cap - pl.g.nt, 64 * o.extra_waves);
+                pl.g.nt += pl.g.u0;
+            }
+        }
     }
     const WsLayout wl = ws_layout(num_tours, group_size);
     unsigned char* w8 = static_cast<unsigned char*>(ws);
@@ -1016,6 +1026,7 @@ extern "C" int tsp2opt_debug_tune(int32_t what, int32_t value)
     else if (what == 7) o.part_sh = value < 0 ? 0 : value > 6 ? 6 : value;
     else if (what == 8) o.half_units = value ? 1 : 0;
     else if (what == 9) o.wide_few = value ? 1 : 0;
+    else if (what == 10) o.extra_waves = value < 0 ? 0 : value > 12 ? 12 : value;
     else return fail(TSP2OPT_E_ARG, "unknown tuning knob");
     return 0;
 }

@@ -33,6 +33,8 @@ struct Geo {                          // launch geometry of the filter sweep (ho
     int lcap;                         // capacity of the changed-tile list
     float eps2;                       // 2*eps of the filter, in scaled units
     float inv_gpl;                    // 1 / GPl: unit -> (row segment, lane group) without an integer division
+    int u0;                           // cached path: lanes u0 .. u0 + GPl * NS - 1 own the units (lanes below u0 -- the oldest
+                                      // waves, which the SIMD arbiter favours -- only apply reversals and recompute listed tiles)
 };
 
 // u / GPl for 0 <= u < 2048, GPl <= 255 (exact: (u + 0.5) / GPl is at least 0.5 / 255 away from an integer,

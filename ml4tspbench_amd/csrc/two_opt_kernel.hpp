@@ -256,7 +256,7 @@ template <bool CL>
 __device__ __forceinline__ Unit lane_unit(const Geo& g, int tid)
 {
     Unit un{-1, 0, 0};
-    if (tid < g.GPl * g.NS) {
+    if (tid >= 0 && tid < g.GPl * g.NS) {
         const int s = div_gpl(g, tid);
         un.gpl = tid - s * g.GPl;
         un.rq0 = s * (g.MS >> 1);
@@ -307,6 +307,7 @@ __device__ __forceinline__ float funkey(unsigned k)
 template <int Q, bool CL, typename T>
 __device__ __forceinline__ void filter_sweep_cached(const View<T>& v, const Geo& g, int tid)
 {
+    tid -= g.u0;                                        // the lane's unit number
     const Unit un = lane_unit<CL>(g, tid);
     if (un.gp < 0) return;
     const int MS2 = g.MS >> 1;
@@ -336,7 +337,8 @@ __device__ __forceinline__ void filter_sweep_cached(const View<T>& v, const Geo&
 template <bool CL, typename T>
 __device__ __forceinline__ void mark_touched(const View<T>& v, const Geo& g, int tid, int lo0, int len)
 {
-    const Unit un = lane_unit<CL>(g, tid);
+    const int ut = tid - g.u0;                          // the lane's unit number
+    const Unit un = lane_unit<CL>(g, ut);
     const int MS2 = g.MS >> 1;
     int i = lo0 - 1, j = lo0 + len - 1;                 // window positions [i, j] (+ k n) read changed values
     if (j >= g.n) { i -= g.n; j -= g.n; }               // (uniform) the earliest copy that reaches the window
@@ -363,7 +365,7 @@ __device__ __forceinline__ void mark_touched(const View<T>& v, const Geo& g, int
 #pragma unroll
             for (int k = 0; k < 8; ++k) km = ((skip >> (m0 + k)) & 1u) ? km : (c[k] < km ? c[k] : km);
         }
-        v.Mu[tid] = km;
+        v.Mu[ut] = km;
     }
     // compaction: prefix sum of the lanes' counts -> one atomic per wave -> every lane writes its run
     const unsigned cnt = (unsigned)__popc(mask);
