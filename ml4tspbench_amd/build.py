@@ -30,8 +30,8 @@ OBJ_DIR = os.path.join(ROOT, "build")
 UNIT_DEPS = {
     "tsp2opt.hip": ("wave_reduce.hpp", "host_util.hpp", "two_opt_common.hpp", "two_opt_kernel.hpp",
                     "two_opt_band.hpp", "two_opt_aux.hpp"),
-    "greedy.hip": ("wave_reduce.hpp", "host_util.hpp"),
-    "greedy_sparse.hip": ("wave_reduce.hpp", "host_util.hpp"),
+    "greedy.hip": ("wave_reduce.hpp", "host_util.hpp", "greedy_walk.hpp"),
+    "greedy_sparse.hip": ("wave_reduce.hpp", "host_util.hpp", "greedy_walk.hpp"),
     "ls_ops.hip": ("wave_reduce.hpp", "host_util.hpp"),
 }
 

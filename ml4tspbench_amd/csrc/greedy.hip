@@ -39,6 +39,7 @@
 #include "tsp2opt.h"
 #include "host_util.hpp"
 #include "wave_reduce.hpp"
+#include "greedy_walk.hpp"
 
 #pragma clang fp contract(off)
 
@@ -585,36 +586,44 @@ __global__ void __launch_bounds__(1024) k_greedy(const float* __restrict__ Kd, c
         atomicAdd(&g_greedy_prof[6], rounds);
         atomicAdd(&g_greedy_prof[7], serial_rounds);
     }
-    if (tid >= 64) return;                              // the rest is short and serial: wave 0
     // closing edge between the two remaining endpoints (cython_merge.pyx:99-102), then the walk of
     // greedy_search.py:65-73 (from node 0, never back to the previous node, larger index first) over an LDS
-    // copy of the neighbour table
-    int a = -1, c = -1;
-    for (int g = 0; g < G; ++g) {
-        const int k = (g << 6) + lane;
-        unsigned long long bal = __ballot(k < n && L.deg[k] < 2);
-        while (bal) {
-            const int k2 = (g << 6) + __ffsll((long long)bal) - 1;
-            bal &= bal - 1;
-            if (a < 0) a = k2; else c = k2;
+    // copy of the neighbour table: a parallel list ranking (greedy_walk.hpp), or -- should the merge ever end
+    // without a Hamiltonian path -- the serial walk, step by step like the reference
+    if (tid < 64) {
+        int a = -1, c = -1;
+        for (int g = 0; g < G; ++g) {
+            const int k = (g << 6) + lane;
+            unsigned long long bal = __ballot(k < n && L.deg[k] < 2);
+            while (bal) {
+                const int k2 = (g << 6) + __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                if (a < 0) a = k2; else c = k2;
+            }
         }
+        if (lane == 0) { ctl[0] = a; ctl[1] = c; }
     }
-    __threadfence_block();
+    __syncthreads();                                        // (also: the merge loop's last writes of nb)
+    const int a = ctl[0], c = ctl[1];
     unsigned* nbl = reinterpret_cast<unsigned*>(L.key);    // the candidates are dead by now
-    for (int k = lane; k < n; k += 64) {
+    bool whole = true;
+    for (int k = tid; k < n; k += T) {
         unsigned lo = nb[2 * k], hi = nb[2 * k + 1];
         if (a >= 0 && c >= 0) {
             if (k == a) { if (lo == 0xffffu) lo = (unsigned)c; else hi = (unsigned)c; }
             if (k == c) { if (lo == 0xffffu) lo = (unsigned)a; else hi = (unsigned)a; }
         }
         nbl[k] = lo | (hi << 16);
+        whole = whole && lo != 0xffffu && hi != 0xffffu && lo != hi;
     }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    if (lane < 2) {
+    int64_t* t = tours + (size_t)b * (size_t)(n + 1);
+    if (__syncthreads_and(whole ? 1 : 0) && merges == n - 1 && walk_parallel_fits(n, T)) {      // (uniform)
+        walk_parallel(nbl, reinterpret_cast<unsigned*>(L.cj), n, tid, T, t);    // cj .. lp: 8 B per node, all dead
+        return;
+    }
+    if (lane < 2 && tid < 64) {
         // lane 0 walks from node 0 towards its larger neighbour and fills positions 1 .. n/2, lane 1 walks the
         // other way round and fills n-1 .. n/2+1
-        int64_t* t = tours + (size_t)b * (size_t)(n + 1);
         const int h = n >> 1, steps = lane == 0 ? h : n - 1 - h;
         int prev = -1, cur = 0;
         if (lane == 0) { t[0] = 0; t[n] = n == 2 ? -1 : 0; }   // n = 2: the reference's walk has no step left (it raises); -1 like the oracle

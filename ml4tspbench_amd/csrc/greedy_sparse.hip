@@ -34,6 +34,7 @@
 #include "tsp2opt.h"
 #include "host_util.hpp"
 #include "wave_reduce.hpp"
+#include "greedy_walk.hpp"
 
 #pragma clang fp contract(off)
 
@@ -64,24 +65,48 @@ __device__ __forceinline__ SrcRun src_run(int key, int lane)
     return r;
 }
 
-__global__ void __launch_bounds__(256) k_sp_count(const int64_t* __restrict__ ei, int64_t E, int n, int* __restrict__ cnt,
-                                                  int* __restrict__ err)
+// Counters and cursors are privatised: a workgroup takes a chunk of one instance's edges, counts (or hands out
+// positions) in an LDS table of n words with LDS atomics and touches global memory once per row it met -- one
+// global atomic per (chunk, row) instead of two per edge (16 x 500 000 edges: 0.34 ms -> see profiles/).
+constexpr int kSpChunkThreads = 1024;
+
+// edge e of the chunk -> (a, b, valid); out-of-range indices are reported in *err (bit 0) when err != nullptr
+__device__ __forceinline__ bool sp_edge(const int64_t* __restrict__ ei, int64_t E, int n, int64_t e, int64_t e1,
+                                        int64_t& a, int64_t& b, int* __restrict__ err)
 {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    ei += (size_t)blockIdx.y * 2 * (size_t)E;
-    cnt += (size_t)blockIdx.y * ((size_t)n + 1);
-    int64_t a = -1, b = -1;
-    if (e < E) {
+    a = -1; b = -1;
+    if (e < e1) {
         a = ei[e];
         b = ei[E + e];
-        if (a < 0 || a >= n || b < 0 || b >= n) { atomicOr(err, 1); a = -1; }
+        if (a < 0 || a >= n || b < 0 || b >= n) { if (err) atomicOr(err, 1); a = -1; }
     }
-    const bool valid = a >= 0 && a != b;                // the diagonal is never a valid edge
-    const SrcRun r = src_run(valid ? (int)a : -1 - lane, lane);
-    if (valid) {
-        if (r.head == lane) atomicAdd(&cnt[a], r.len);
-        atomicAdd(&cnt[b], 1);
+    return a >= 0 && a != b;                            // the diagonal is never a valid edge
+}
+
+__global__ void __launch_bounds__(kSpChunkThreads) k_sp_count(const int64_t* __restrict__ ei, int64_t E, int n,
+                                                              int* __restrict__ cnt, int* __restrict__ err, int chunk)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* hist = reinterpret_cast<int*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, T = blockDim.x;
+    ei += (size_t)blockIdx.y * 2 * (size_t)E;
+    cnt += (size_t)blockIdx.y * ((size_t)n + 1);
+    const int64_t e0 = (int64_t)blockIdx.x * chunk, e1 = e0 + chunk < E ? e0 + chunk : E;
+    for (int i = tid; i < n; i += T) hist[i] = 0;
+    __syncthreads();
+    for (int64_t eb = e0; eb < e1; eb += T) {           // (uniform trip count: src_run shuffles across the wave)
+        int64_t a, b;
+        const bool valid = sp_edge(ei, E, n, eb + tid, e1, a, b, err);
+        const SrcRun r = src_run(valid ? (int)a : -1 - lane, lane);
+        if (valid) {
+            if (r.head == lane) atomicAdd(&hist[a], r.len);
+            atomicAdd(&hist[b], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += T) {
+        const int c = hist[i];
+        if (c) atomicAdd(&cnt[i], c);
     }
 }
 
@@ -121,34 +146,57 @@ __global__ void __launch_bounds__(1024) k_sp_scan(const int* __restrict__ cnt, i
     if (tid == 1023) off[n] = part[1023];
 }
 
-__global__ void __launch_bounds__(256) k_sp_fill(const int64_t* __restrict__ ei, int64_t E, int n, const int* __restrict__ off,
-                                                 int* __restrict__ cur, uint16_t* __restrict__ ent_j, int* __restrict__ ent_e)
+// (entries land in their row in no particular order: k_sp_rowsort orders every row afterwards)
+__global__ void __launch_bounds__(kSpChunkThreads) k_sp_fill(const int64_t* __restrict__ ei, int64_t E, int n,
+                                                             const int* __restrict__ off, int* __restrict__ cur,
+                                                             uint16_t* __restrict__ ent_j, int* __restrict__ ent_e, int chunk)
 {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* hist = reinterpret_cast<int*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, T = blockDim.x;
     ei += (size_t)blockIdx.y * 2 * (size_t)E;
     off += (size_t)blockIdx.y * ((size_t)n + 1);
     cur += (size_t)blockIdx.y * ((size_t)n + 1);
     ent_j += (size_t)blockIdx.y * 2 * (size_t)E;
     ent_e += (size_t)blockIdx.y * 2 * (size_t)E;
-    int64_t a = -1, b = -1;
-    if (e < E) {
-        a = ei[e];
-        b = ei[E + e];
-        if (a < 0 || a >= n || b < 0 || b >= n) a = -1;
+    const int64_t e0 = (int64_t)blockIdx.x * chunk, e1 = e0 + chunk < E ? e0 + chunk : E;
+    for (int i = tid; i < n; i += T) hist[i] = 0;
+    __syncthreads();
+    // this chunk's entries per row ...
+    for (int64_t eb = e0; eb < e1; eb += T) {
+        int64_t a, b;
+        const bool valid = sp_edge(ei, E, n, eb + tid, e1, a, b, nullptr);
+        const SrcRun r = src_run(valid ? (int)a : -1 - lane, lane);
+        if (valid) {
+            if (r.head == lane) atomicAdd(&hist[a], r.len);
+            atomicAdd(&hist[b], 1);
+        }
     }
-    const bool valid = a >= 0 && a != b;
-    const SrcRun r = src_run(valid ? (int)a : -1 - lane, lane);
-    int base = 0;
-    if (valid && r.head == lane) base = atomicAdd(&cur[a], r.len);
-    base = __shfl(base, r.head);
-    if (!valid) return;
-    int pos = off[a] + base + (lane - r.head);
-    ent_j[pos] = (uint16_t)b;
-    ent_e[pos] = (int)(2 * e);                          // row a holds (a, b): forward, the first coo matrix
-    pos = off[b] + atomicAdd(&cur[b], 1);
-    ent_j[pos] = (uint16_t)a;
-    ent_e[pos] = (int)(2 * e + 1);                      // row b holds the same edge transposed: the second
+    __syncthreads();
+    // ... reserve that many places of the row: the table now holds the chunk's first place in every row ...
+    for (int i = tid; i < n; i += T) {
+        const int c = hist[i];
+        hist[i] = c ? off[i] + atomicAdd(&cur[i], c) : 0;
+    }
+    __syncthreads();
+    // ... and hand them out
+    for (int64_t eb = e0; eb < e1; eb += T) {
+        const int64_t e = eb + tid;
+        int64_t a, b;
+        const bool valid = sp_edge(ei, E, n, e, e1, a, b, nullptr);
+        const SrcRun r = src_run(valid ? (int)a : -1 - lane, lane);
+        int base = 0;
+        if (valid && r.head == lane) base = atomicAdd(&hist[a], r.len);
+        base = __shfl(base, r.head);
+        if (valid) {
+            int pos = base + (lane - r.head);
+            ent_j[pos] = (uint16_t)b;
+            ent_e[pos] = (int)(2 * e);                  // row a holds (a, b): forward, the first coo matrix
+            pos = atomicAdd(&hist[b], 1);
+            ent_j[pos] = (uint16_t)a;
+            ent_e[pos] = (int)(2 * e + 1);              // row b holds the same edge transposed: the second
+        }
+    }
 }
 
 // one wave per row: entries ordered by (partner, edge id, direction); ucnt[i] = distinct partners, and the
@@ -532,7 +580,6 @@ __global__ void __launch_bounds__(1024) k_greedy_sparse(const uint16_t* __restri
         __syncthreads();
     }
     __syncthreads();
-    if (tid >= 64) return;                              // the rest is short and serial: wave 0
     // ---- the pairs without a positive sum.  Their key is -0.0 / d: -0.0, all tied, the lower flat index
     // i*n + j first -- except where d is not a positive number (coincident points, squares that underflow,
     // NaN coordinates): there it is NaN, which numpy sorts after everything else (tied again, by index).  Two
@@ -542,72 +589,85 @@ __global__ void __launch_bounds__(1024) k_greedy_sparse(const uint16_t* __restri
     // ascending sweep over the open nodes serves all merges of a pass.
     const unsigned long long t2 = wall_clock64();
     const int listed_merges = merges;
-    for (int pass = 0; pass < 2 && merges < n - 1; ++pass) {
-        int i = -1, from = 0;                           // current node; nodes below `from` are done for this pass
-        while (merges < n - 1) {
-            if (i < 0 || L.deg[i] >= 2) {               // (re)locate the smallest open node at or above `from`
-                i = -1;
-                for (int g = from >> 6; g < G; ++g) {
+    if (tid < 64) {                                     // short and serial: wave 0
+        for (int pass = 0; pass < 2 && merges < n - 1; ++pass) {
+            int i = -1, from = 0;                           // current node; nodes below `from` are done for this pass
+            while (merges < n - 1) {
+                if (i < 0 || L.deg[i] >= 2) {               // (re)locate the smallest open node at or above `from`
+                    i = -1;
+                    for (int g = from >> 6; g < G; ++g) {
+                        const int k = (g << 6) + lane;
+                        const unsigned long long bal = __ballot(k < n && k >= from && L.deg[k] < 2);
+                        if (bal) { i = (g << 6) + __ffsll((long long)bal) - 1; break; }
+                    }
+                    if (i < 0) break;
+                    from = i;
+                }
+                const int oe = L.oend[i];
+                const double xi = M.P[2 * i], yi = M.P[2 * i + 1];
+                int j = -1;
+                for (int g = i >> 6; g < G && j < 0; ++g) {
                     const int k = (g << 6) + lane;
-                    const unsigned long long bal = __ballot(k < n && k >= from && L.deg[k] < 2);
-                    if (bal) { i = (g << 6) + __ffsll((long long)bal) - 1; break; }
+                    unsigned long long bal = __ballot(k < n && k > i && L.deg[k] < 2 && !(k == oe && oe != i));
+                    while (bal) {                           // (wave-uniform: every lane tests the same candidate)
+                        const int c = (g << 6) + __ffsll((long long)bal) - 1;
+                        bal &= bal - 1;
+                        const double dx = xi - M.P[2 * c], dy = yi - M.P[2 * c + 1];
+                        const bool nankey = !(dx * dx + dy * dy > 0.0);     // sqrt(0) = 0 and -0.0 / 0 is NaN
+                        if (nankey == (pass == 1)) { j = c; break; }
+                    }
                 }
-                if (i < 0) break;
-                from = i;
-            }
-            const int oe = L.oend[i];
-            const double xi = M.P[2 * i], yi = M.P[2 * i + 1];
-            int j = -1;
-            for (int g = i >> 6; g < G && j < 0; ++g) {
-                const int k = (g << 6) + lane;
-                unsigned long long bal = __ballot(k < n && k > i && L.deg[k] < 2 && !(k == oe && oe != i));
-                while (bal) {                           // (wave-uniform: every lane tests the same candidate)
-                    const int c = (g << 6) + __ffsll((long long)bal) - 1;
-                    bal &= bal - 1;
-                    const double dx = xi - M.P[2 * c], dy = yi - M.P[2 * c + 1];
-                    const bool nankey = !(dx * dx + dy * dy > 0.0);     // sqrt(0) = 0 and -0.0 / 0 is NaN
-                    if (nankey == (pass == 1)) { j = c; break; }
+                if (j < 0) {                                // nothing for i in this pass: on to the next open node
+                    from = i + 1;
+                    i = -1;
+                    continue;
                 }
+                if (lane == 0) sp_link(L, nb, i, j);
+                ++merges;
+                __builtin_amdgcn_wave_barrier();
             }
-            if (j < 0) {                                // nothing for i in this pass: on to the next open node
-                from = i + 1;
-                i = -1;
-                continue;
-            }
-            if (lane == 0) sp_link(L, nb, i, j);
-            ++merges;
-            __builtin_amdgcn_wave_barrier();
         }
+        if (lane == 0) ctl[0] = merges;
     }
+    __syncthreads();
+    merges = ctl[0];
     const unsigned long long t3 = wall_clock64();
     // closing edge between the two remaining ends, then the walk of greedy_search.py:65-73 over an LDS copy
-    // of the neighbour table
-    int a = -1, c = -1;
-    for (int g = 0; g < G; ++g) {
-        const int k = (g << 6) + lane;
-        unsigned long long bal = __ballot(k < n && L.deg[k] < 2);
-        while (bal) {
-            const int k2 = (g << 6) + __ffsll((long long)bal) - 1;
-            bal &= bal - 1;
-            if (a < 0) a = k2; else c = k2;
+    // of the neighbour table: a parallel list ranking (greedy_walk.hpp), or -- should the merge ever end
+    // without a Hamiltonian path -- the serial walk, step by step like the reference
+    if (tid < 64) {
+        int a = -1, c = -1;
+        for (int g = 0; g < G; ++g) {
+            const int k = (g << 6) + lane;
+            unsigned long long bal = __ballot(k < n && L.deg[k] < 2);
+            while (bal) {
+                const int k2 = (g << 6) + __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                if (a < 0) a = k2; else c = k2;
+            }
         }
+        if (lane == 0) { red_i[0] = (unsigned)a; red_i[1] = (unsigned)c; }
     }
-    __threadfence_block();
-    unsigned* nbl = L.pos;                              // the cursors are dead by now
-    for (int k = lane; k < n; k += 64) {
+    __syncthreads();
+    const int a = (int)red_i[0], c = (int)red_i[1];
+    unsigned* nbl = reinterpret_cast<unsigned*>(L.key);    // the candidates are dead by now
+    bool whole = true;
+    for (int k = tid; k < n; k += T) {
         unsigned lo = nb[2 * k], hi = nb[2 * k + 1];
         if (a >= 0 && c >= 0) {
             if (k == a) { if (lo == 0xffffu) lo = (unsigned)c; else hi = (unsigned)c; }
             if (k == c) { if (lo == 0xffffu) lo = (unsigned)a; else hi = (unsigned)a; }
         }
         nbl[k] = lo | (hi << 16);
+        whole = whole && lo != 0xffffu && hi != 0xffffu && lo != hi;
     }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    if (lane < 2) {
+    int64_t* t = tours + (size_t)b * (size_t)(n + 1);
+    const bool par = __syncthreads_and(whole ? 1 : 0) && merges == n - 1 && walk_parallel_fits(n, T);   // (uniform)
+    if (par) {
+        walk_parallel(nbl, L.pos, n, tid, T, t);           // pos, cj, oend: 8 B per node, all dead
+    } else if (lane < 2 && tid < 64) {
         // lane 0 walks from node 0 towards its larger neighbour and fills positions 1 .. n/2, lane 1 walks the
         // other way round and fills n-1 .. n/2+1
-        int64_t* t = tours + (size_t)b * (size_t)(n + 1);
         const int h = n >> 1, steps = lane == 0 ? h : n - 1 - h;
         int prev = -1, cur = 0;
         if (lane == 0) { t[0] = 0; t[n] = n == 2 ? -1 : 0; }   // n = 2: the reference's walk has no step left (it raises); -1 like the oracle
@@ -622,7 +682,7 @@ __global__ void __launch_bounds__(1024) k_greedy_sparse(const uint16_t* __restri
             cur = best < 0 ? 0 : best;
         }
     }
-    if (b == 0 && lane == 0 && dbg) {                   // diagnostics of heat map 0 (10 ns ticks, counts)
+    if (b == 0 && tid == 0 && dbg) {                    // diagnostics of heat map 0 (10 ns ticks, counts)
         const unsigned long long t4 = wall_clock64();
         dbg[0] = t1 - t0; dbg[1] = t2 - t1; dbg[2] = t3 - t2; dbg[3] = t4 - t3;
         dbg[4] = rounds; dbg[5] = serial_rounds; dbg[6] = 0; dbg[7] = (unsigned long long)listed_merges;
@@ -686,9 +746,12 @@ int greedy_sparse_t(const void* values, const int64_t* ei, const double* points,
     uint16_t* lj = reinterpret_cast<uint16_t*>(w8 + wl.off_lists);
     float* lk = reinterpret_cast<float*>(w8 + wl.off_lk);
     HIP_TRY(hipMemsetAsync(w8, 0, wl.off_off, stream));                 // err + cnt
-    const unsigned eg = (unsigned)std::max<int64_t>((E + 255) / 256, 1);   // E = 0: one idle block
+    // chunks of at least 4 n edges (a chunk pays n table entries on entry and on exit), at most 65536
+    const int chunk = (int)std::min<int64_t>(65536, std::max<int64_t>(4 * (int64_t)n, 8192));
+    const unsigned eg = (unsigned)std::max<int64_t>((E + chunk - 1) / chunk, 1);   // E = 0: one idle block
     const unsigned ig = (unsigned)inst;
-    hipLaunchKernelGGL(k_sp_count, dim3(eg, ig), dim3(256), 0, stream, ei, E, n, cnt, err);
+    const size_t hlds = sizeof(int) * (size_t)n;
+    hipLaunchKernelGGL(k_sp_count, dim3(eg, ig), dim3(kSpChunkThreads), hlds, stream, ei, E, n, cnt, err, chunk);
     hipLaunchKernelGGL(k_sp_scan, dim3(ig), dim3(1024), 0, stream, cnt, off, cur, n, kSpMaxRow, err);
     // the error word and the longest row (it sizes the LDS of the two row kernels) are known after the scan
     int eh[2] = {0, 0};
@@ -704,7 +767,7 @@ int greedy_sparse_t(const void* values, const int64_t* ei, const double* points,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_rowkeys<H>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)klds));
-    hipLaunchKernelGGL(k_sp_fill, dim3(eg, ig), dim3(256), 0, stream, ei, E, n, off, cur, entj, ente);
+    hipLaunchKernelGGL(k_sp_fill, dim3(eg, ig), dim3(kSpChunkThreads), hlds, stream, ei, E, n, off, cur, entj, ente, chunk);
     hipLaunchKernelGGL(k_sp_rowsort, dim3((unsigned)n, ig), dim3(64), slds, stream, off, entj, ente, srtj, srte, ucnt, n, E);
     hipLaunchKernelGGL(k_sp_scan, dim3(ig), dim3(1024), 0, stream, ucnt, uoff, (int*)nullptr, n, 0, err);
     hipLaunchKernelGGL(k_sp_rowkeys<H>, dim3((unsigned)n, ig), dim3(64), klds, stream,

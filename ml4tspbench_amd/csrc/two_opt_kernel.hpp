@@ -585,7 +585,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
                     const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)chunk, src);
                     float d;
                     unsigned di;
-                    filter_chunk_pair<Q>(v, g, id, lane, d, di);
+                    filter_chunk_pair_b<Q>(v, g, id, lane, d, di);
                     if (g.half && lane >= 32) d = INFINITY;         // a macro step has 32 pairs
                     if (d <= thr) {
                         multi = multi || (fidx != 0xffffffffu && fidx != di);
