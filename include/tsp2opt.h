@@ -261,7 +261,8 @@ int tsp2opt_gls_rounds(const double* points, int64_t* tours, int64_t* best_tours
 int tsp2opt_sqrt_check(const void* in, void* out, int64_t count, int32_t dtype, int32_t device,
                        void* hip_stream);
 
-/* Kernel variant / launch geometry the library would pick for n (for logs and tests).
+/* Kernel variant / launch geometry the library would pick for n (for logs and tests): the geometry of batches with
+ * more tours than compute units (smaller batches get two to four times the threads per tour).
  * out[0]=threads per workgroup, out[1]=fast-path class (0: exact-only kernel), out[2]=LDS bytes,
  * out[3]=row segments, out[4]=diagonal groups, out[5]=macro steps, out[6]=resident workgroups/CU */
 int tsp2opt_plan(int32_t n, int32_t dtype, int32_t device, int32_t* out7);
@@ -316,7 +317,9 @@ int tsp2opt_debug_cluster_inc(int32_t on);
  * what = 6: 1 replays coupled calls (group_size > 1) entirely in the lock-step kernel (tests; default 0);
  * what = 7: band cluster kernel, log2 of the macro steps per part when a listed cache group is recomputed
  * (default 3); what = 8: 0 plans small tours without the tile cache in whole tiles per lane instead of macro-step
- * units (default 1).  The knobs belong to the calling thread. */
+ * units (default 1); what = 9: 0 plans a batch of at most one tour per compute unit like a large batch instead of
+ * with two to four times the threads per tour (default 1; results never depend on it: tests run both); what = 10:
+ * waves without a unit in that wide geometry, 0..12 (default 4).  The knobs belong to the calling thread. */
 int tsp2opt_debug_tune(int32_t what, int32_t value);
 /* Geometry the library would pick for `num_tours` tours of n nodes on a device with `cus` compute
  * units when several workgroups share a tour (host-only, for logs and tests):

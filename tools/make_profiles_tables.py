@@ -70,8 +70,8 @@ head = (f"Headline (`{TAG}_bench_tsp500.json`): {b['value']:.3e} pair-deltas/s, 
 text = "\n".join([head, "", "Kernel traces: " + "; ".join(ks) + ".", "", *t1, "", *t2, "", *t3])
 path = os.path.join(P, "README.md")
 src = open(path).read()
-new = re.sub(r"<!-- BEGIN GENERATED r02 -->.*?<!-- END GENERATED r02 -->",
-             "<!-- BEGIN GENERATED r02 -->\n" + text + "\n<!-- END GENERATED r02 -->", src, flags=re.S)
+new = re.sub(rf"<!-- BEGIN GENERATED {TAG} -->.*?<!-- END GENERATED {TAG} -->",
+             lambda m: f"<!-- BEGIN GENERATED {TAG} -->\n" + text + f"\n<!-- END GENERATED {TAG} -->", src, flags=re.S)
 assert new != src or text in src, "markers not found"
 open(path, "w").write(new)
 print(text)
