@@ -130,6 +130,7 @@ struct Ctl {                          // LDS control block (first bytes of dynam
     float spd;                        // cached filter value of the pair (0, n-1) (thread 0; find_best)
     double cx, cy, sc;
     double isc;                       // 1 / sc (a power of two, exact)
+    float tsc;                        // (float)(1e-6 * sc): the reference's threshold in filter units
 };
 
 // ------------------------------------------------------------------------------------------

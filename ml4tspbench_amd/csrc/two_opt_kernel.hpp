@@ -344,7 +344,10 @@ __device__ __forceinline__ void mark_touched(const View<T>& v, const Geo& g, int
     if (j >= g.n) { i -= g.n; j -= g.n; }               // (uniform) the earliest copy that reaches the window
     unsigned mask = 0u;                                 // touched tiles of the lane's unit (MS2 <= 32)
     if (un.gp >= 0) {
+        // (two to four copies.  The counter is opaque to the compiler, which otherwise computes the trip count up front:
+        //  a division by n through a reciprocal that it keeps in scratch memory -- a scratch load per iteration)
         for (int lo = i, hi = j; lo < g.W; lo += g.n, hi += g.n) {
+            asm volatile("" : "+v"(lo));
             mask |= bit_range32((lo >> 3) - un.rq0, (hi >> 3) - un.rq0, MS2);                              // rows
             mask |= bit_range32(((lo - 9) >> 3) - un.gp - un.rq0, ((hi - 2) >> 3) - un.gp - un.rq0, MS2);  // columns
         }
@@ -406,6 +409,8 @@ __device__ __forceinline__ void refresh_cached(const View<T>& v, const Geo& g, i
     Ctl* ctl = v.ctl;
     FINE_START_G(pf, 0x000e);
     const unsigned nl = ctl->nlist;
+    // (the lane's first list entry is read before nl is known -- one LDS round trip instead of two on the chain;
+    //  whatever an unused slot holds is never looked at)
     __builtin_amdgcn_s_setprio(0);
     if (last == kFullSweep || nl > (unsigned)g.lcap) {      // (uniform) first sweep, or most of the tour moved
         filter_sweep_cached<Q, CL>(v, g, tid);
@@ -508,6 +513,16 @@ __device__ __forceinline__ void filter_chunk_pair_b(const View<T>& v, const Geo&
     idx = pair_index(v, g.n, wrap3(rw, g.n), wrap3(cw, g.n));
 }
 
+// The margin of the fp32 decisions (eps2 = 2 eps; 25 % extra), recomputed WHERE IT IS USED: left alone the compiler
+// hoists the loop-invariant product (and its double) out of the improvement loop and, the kernel being at its
+// register limit, keeps them in scratch memory -- two scratch loads on every iteration's decision chain.
+__device__ __forceinline__ float decision_eps(const Geo& g)
+{
+    float e2 = g.eps2;
+    asm volatile("" : "+v"(e2));
+    return 0.625f * e2;
+}
+
 // One full argmin (the reference's per-tour torch.min / torch.argmin, two_opt.py:35-38) for geometries
 // WITHOUT the tile cache (tiny tours with one tile per lane; N where the cache does not fit) and the
 // exact-only kernel (Q = 0); select_cached below is the same decision on top of the cache.
@@ -553,7 +568,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
             // moves below -1e-6 are ever applied (independent termination), so pairs whose filter value
             // proves delta >= -1e-6 need no exact evaluation: without this clamp a workgroup whose tiles
             // hold no improving move would chase near-ties among its non-improving minima.
-            thr = fminf(thr, (float)(-1.0e-6 * ctl->sc) + 0.625f * g.eps2);
+            thr = fminf(thr, -ctl->tsc + decision_eps(g));
         }
         const unsigned long long cmask0 = __ballot(a1 <= thr);
         int amb = __ballot(a2 <= thr) != 0ull || __popcll(cmask0) > 8;
@@ -572,8 +587,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
             // IS the reference's argmin, and if its value is below -1e-6 by more than eps the move is
             // certain without any exact arithmetic.  Likewise a window that lies above -1e-6 + eps
             // proves convergence.  Anything else falls through to the exact stage.
-            const float thr_scale = (float)(1.0e-6 * ctl->sc);
-            const float eps = 0.625f * g.eps2;                  // eps2 = 2 eps; 25 % extra margin
+            const float thr_scale = ctl->tsc;
             float fd = INFINITY;
             unsigned fidx = 0xffffffffu;
             bool multi = false;
@@ -638,6 +652,7 @@ __device__ void find_best(const View<T>& v, const Geo& g, int tid, bool need_exa
             unique = unique && !(fl & 2) && bi != 0xffffffffu;
             FINE(pf, 6);                                    // wave + workgroup reduction of the fp32 stage
             if (!amb) {
+                const float eps = decision_eps(g);
                 if (unique && (float)bd < -thr_scale - eps) {           // certain improving move
                     e = ((double)(float)bd + (double)eps) * ctl->isc;   // an upper bound, < -1e-6
                     idx = bi;
@@ -777,15 +792,14 @@ constexpr int kStage1Tiles = 8;     // more candidate tiles than this: heavy tie
 
 // window of the filter values that can hold the argmin, from the unit minima (every lane of a wave)
 template <bool CL>
-__device__ __forceinline__ float window_threshold(const UnitMinima& um, const Geo& g, float thr_scale, float eps,
-                                                  float& m)
+__device__ __forceinline__ float window_threshold(const UnitMinima& um, const Geo& g, float thr_scale, float& m)
 {
     m = funkey(unit_minimum(um));
     float thr = m + g.eps2;
     // CL: this workgroup sees only its own tiles, whose minimum may be far above the tour's.  Only moves
     // below -1e-6 are ever applied (independent termination), so pairs whose filter value proves
     // delta >= -1e-6 need no exact evaluation.
-    if constexpr (CL) thr = fminf(thr, -thr_scale + eps);
+    if constexpr (CL) thr = fminf(thr, -thr_scale + decision_eps(g));
     return thr;
 }
 
@@ -798,24 +812,23 @@ __device__ __forceinline__ float window_threshold(const UnitMinima& um, const Ge
 // below -1e-6 for a certain move), idx = packed (i,j) or kNoMove.  CL: this workgroup's tiles only,
 // always exact (the result is compared across workgroups).
 template <typename T, int Q, bool CL>
-__device__ void select_cached(const View<T>& v, const Geo& g, int tid, bool need_exact_sign, int round,
+__device__ void select_cached(const View<T>& v, const Geo& g, int tid, bool need_exact_sign, int turn,
                               double& e, unsigned& idx, Prof& pf)
 {
     Ctl* ctl = v.ctl;
     const int nw = g.nt >> 6, lane = tid & 63, wv = tid >> 6;
-    const float eps = 0.625f * g.eps2;                  // eps2 = 2 eps; 25 % extra margin
-    const bool mine = CL || nw == 1 || wv == round % nw;
+    const bool mine = CL || nw == 1 || wv == turn;      // turn = iteration mod waves (kept by the caller: no division)
     int code = 0;                                       // 0: (e, idx) final, 1: exact stage, 2: heavy ties
     e = 0.0;
     idx = kNoMove;
     FINE_START_G(pf, 0x02f0);
     if (mine) {
         const UnitMinima um = load_unit_minima(v, g, lane);     // one LDS round trip together with sc / spd
-        const double scale = ctl->sc, iscale = ctl->isc;
+        const double iscale = ctl->isc;
         const float spd = ctl->spd;
-        const float thr_scale = (float)(1.0e-6 * scale);
+        const float thr_scale = ctl->tsc;
         float m;
-        const float thr = window_threshold<CL>(um, g, thr_scale, eps, m);
+        const float thr = window_threshold<CL>(um, g, thr_scale, m);
         FINE(pf, 4);                                    // workgroup minimum of the filter
         if constexpr (CL) {
             const int nct = for_each_candidate_tile(v, g, lane, thr, um, kStage1Tiles, [&](unsigned id) {
@@ -849,19 +862,27 @@ __device__ void select_cached(const View<T>& v, const Geo& g, int tid, bool need
 #ifndef TSP2OPT_NO_FASTC
             {
                 const unsigned kthr = fkey(thr);
-                // (ballots: one compare per key and scalar bookkeeping instead of per-lane counters)
-                int c1 = 0, u = 0;
+                // (per-lane counters under wave-uniform chunk guards: three VALU instructions a key)
+                int cnt = 0, first = 0;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 3; c >= 0; --c) {
                     if (c < um.nch) {                                   // (uniform)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
+                        for (int k = 3; k >= 0; --k) {
                             const unsigned key = k == 0 ? um.k[c].x : k == 1 ? um.k[c].y : k == 2 ? um.k[c].z : um.k[c].w;
-                            const unsigned long long b = __ballot(key <= kthr);
-                            c1 += __popcll(b);
-                            if (b) u = 256 * c + 4 * (__ffsll((long long)b) - 1) + k;
+                            const bool hit = key <= kthr;
+                            cnt += hit ? 1 : 0;
+                            first = hit ? 4 * c + k : first;
                         }
                     }
+                }
+                const unsigned long long ub = __ballot(cnt != 0);
+                int c1 = 0, u = 0;
+                if (__popcll(ub) == 1) {
+                    const int src = __ffsll((long long)ub) - 1;
+                    const int f1 = __builtin_amdgcn_readlane(first, src);
+                    c1 = __builtin_amdgcn_readlane(cnt, src);
+                    u = 256 * (f1 >> 2) + 4 * src + (f1 & 3);
                 }
                 {
                     if (c1 == 1) {
@@ -887,6 +908,7 @@ __device__ void select_cached(const View<T>& v, const Geo& g, int tid, bool need
                                     widx = (unsigned)__builtin_amdgcn_readlane((int)di, wl);
                                 }
                                 code = 1;
+                                const float eps = decision_eps(g);
                                 if (wd < -thr_scale - eps) {                            // certain improving move
                                     e = ((double)wd + (double)eps) * iscale;
                                     idx = widx;
@@ -935,6 +957,7 @@ __device__ void select_cached(const View<T>& v, const Geo& g, int tid, bool need
                 const bool wother = __ballot(multi || (fidx != 0xffffffffu && fidx != widx)) != 0ull;
                 const bool unique = !wother && widx != 0xffffffffu;
                 code = 1;
+                const float eps = decision_eps(g);
                 if (unique && wd < -thr_scale - eps) {                  // certain improving move
                     e = ((double)wd + (double)eps) * iscale;            // an upper bound, < -1e-6
                     idx = widx;
@@ -967,7 +990,7 @@ __device__ void select_cached(const View<T>& v, const Geo& g, int tid, bool need
     if (pf.on) { pf.cands += 1; pf.amb += heavy ? 1 : 0; }
     const UnitMinima um = load_unit_minima(v, g, lane);
     float m;
-    const float thr = window_threshold<CL>(um, g, (float)(1.0e-6 * ctl->sc), eps, m);
+    const float thr = window_threshold<CL>(um, g, ctl->tsc, m);
     e = 0.0;
     idx = kNoMove;
     if (!heavy) {
@@ -1424,6 +1447,7 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
             double isc = 1.0;
             if (half > 0.0 && half < INFINITY) { (void)frexp(half, &ex); sc = ldexp(1.0, -ex); isc = ldexp(1.0, ex); }
             ctl->sc = sc;                       // half * sc in [0.5, 1)
+            ctl->tsc = (float)(1.0e-6 * sc);
             ctl->isc = isc;
         }
         __syncthreads();
@@ -1465,7 +1489,7 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
         // ---- improvement loop ----------------------------------------------------------------
         if (pf.on && tid == 0) atomicAdd(&p.stamps[3], clock64() - t_tour);
         const long long t_start = p.time_limit_ticks ? wall_clock64() : 0;
-        int sweeps = 0, st = 0;
+        int sweeps = 0, st = 0, turn = 0;       // turn: which wave decides this iteration (rotates)
         double e;
         unsigned idx;
         if constexpr (Q != 0) {
@@ -1515,7 +1539,8 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
                     FINE(pf, 2);                                                // barrier after the refresh
                     if (tid == 0) ctl->nlist = 0;
                     if (COARSE(pf)) { const unsigned long long t1 = clock64(); pf.sweep += t1 - t0; t0 = t1; }
-                    select_cached<T, Q, CL>(v, g, tid, forced, sweeps, e, idx, pf);    // phase C
+                    select_cached<T, Q, CL>(v, g, tid, forced, turn, e, idx, pf);      // phase C
+                    turn = turn + 1 == (g.nt >> 6) ? 0 : turn + 1;
                     if (COARSE(pf)) pf.select += clock64() - t0;
                 }
             }
