@@ -319,7 +319,8 @@ int tsp2opt_debug_cluster_inc(int32_t on);
  * (default 3); what = 8: 0 plans small tours without the tile cache in whole tiles per lane instead of macro-step
  * units (default 1); what = 9: 0 plans a batch of at most one tour per compute unit like a large batch instead of
  * with two to four times the threads per tour (default 1; results never depend on it: tests run both); what = 10:
- * waves without a unit in that wide geometry, 0..12 (default 4).  The knobs belong to the calling thread. */
+ * waves without a unit in that wide geometry, 0..12 (default 4); what = 13: lanes without a unit in a workgroup of the
+ * full-window cluster (default 64).  The knobs belong to the calling thread. */
 int tsp2opt_debug_tune(int32_t what, int32_t value);
 /* Geometry the library would pick for `num_tours` tours of n nodes on a device with `cus` compute
  * units when several workgroups share a tour (host-only, for logs and tests):

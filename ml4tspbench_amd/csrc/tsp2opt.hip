@@ -94,6 +94,8 @@ struct Opts {
     int stamps = 0;             // phase timers into workspace bytes [64, 256)
     int force_nt = 0;           // threads per workgroup of the single-workgroup plan
     int wide_few = 1;           // twice the threads per tour when the batch has at most one tour per CU
+    int cl_u0 = 64;             // full-window cluster: lanes without a unit (the oldest wave applies the reversal while
+                                // the others mark: TSP-1000 x 128 13.88 -> 13.67 ms; 128: 13.96); tuning knob 13
     int extra_waves = 4;        // ... plus this many waves without a unit (they apply the reversal while the others mark)
     int lcap16 = 13;            // changed-group list capacity of the band cluster kernel, in 1/16 of the groups
     int lcap16s = 13;           // changed-tile list capacity of the one-workgroup / full-window kernel, in 1/16 of the tiles
@@ -264,7 +266,9 @@ Plan make_plan_nt(const Opts& o, int n, int dtype, int cs, int nt_cap)
         // every walked diagonal d = 2..8GP+1 must be a valid pair distance: d <= n-2
         if (GP >= 1 && 8 * GP + 1 <= n - 2) {
             const int R = (n + 3) / 4;                  // macro-step rows needed
-            int NS = nt / GPl;
+            const int u0 = cs > 1 ? std::min(o.cl_u0, nt / 2) : 0;
+            g.u0 = u0;
+            int NS = (nt - u0) / GPl;
             if (NS < 1) NS = 1;
             if (NS > (R + 1) / 2) NS = (R + 1) / 2;
             int MS = (R + NS - 1) / NS;
@@ -289,7 +293,7 @@ Plan make_plan_nt(const Opts& o, int n, int dtype, int cs, int nt_cap)
                 const size_t tiles = (size_t)GPl * NS * (MS / 2);
                 const size_t lcap = tiles * (size_t)o.lcap16s / 16 + 1;
                 const size_t need = align16(4 * tiles) + align16(2 * lcap) + align16(4 * (size_t)GPl * NS);
-                if (MS / 2 >= o.inc_min_tiles && (size_t)NS * (MS / 2) <= 255 && GPl <= 255 && MS / 2 <= 32 && GPl * NS <= nt &&
+                if (MS / 2 >= o.inc_min_tiles && (size_t)NS * (MS / 2) <= 255 && GPl <= 255 && MS / 2 <= 32 && GPl * NS <= nt - u0 &&
                     base + (size_t)g.qclass * 192 + need <= kLdsMax) {
                     g.inc = 1;
                     g.lcap = (int)lcap;
@@ -1026,6 +1030,7 @@ extern "C" int tsp2opt_debug_tune(int32_t what, int32_t value)
     else if (what == 7) o.part_sh = value < 0 ? 0 : value > 6 ? 6 : value;
     else if (what == 8) o.half_units = value ? 1 : 0;
     else if (what == 9) o.wide_few = value ? 1 : 0;
+    else if (what == 13) o.cl_u0 = value < 0 ? 0 : value;
     else if (what == 10) o.extra_waves = value < 0 ? 0 : value > 12 ? 12 : value;
     else return fail(TSP2OPT_E_ARG, "unknown tuning knob");
     return 0;
