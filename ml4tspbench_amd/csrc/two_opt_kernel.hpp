@@ -1144,13 +1144,66 @@ __device__ __forceinline__ void resolve_move(View<T>& v, int n, unsigned idx, in
 }
 
 // reverse the LDS copy's positions lo0 .. lo0 + len - 1 (mod n) and keep the filter window consistent
-template <typename T, int Q>
+template <typename T, int Q, bool SPLIT = true>
 __device__ __forceinline__ void apply_move(const View<T>& v, const Geo& g, int tid, int lo0, int len, Prof& pf)
 {
     const int n = g.n;
     FINE_START_G(pf, 0x0100);
     const int h = len >> 1;                     // position swaps
     const int he = (len - 1) >> 1;              // the interior edges are mirrored (he <= h)
+    if constexpr (Q != 0 && SPLIT) {
+        // Short reversals (at most 31 swaps: nearly all of a tour's late iterations, every one of a 50- or 100-city
+        // tour): FOUR lanes of wave 0 per swap up to 15 swaps -- the two coordinate copies and the two mirrored edges --,
+        // two lanes (one per side, coordinates and edge) up to 31, and two more lanes for the new boundary edges.  A
+        // lane then writes one position's window copies (8 stores) and / or one edge's (4) instead of all 26 of its
+        // swap, and the wave runs the two store shapes once each: about half the instructions of the one-lane-per-swap
+        // loop below, on the chain of every late iteration.  All lanes sit in one wave and read before they write, so
+        // the swaps need no barrier between them, as below.
+        // (Not where unit-less waves apply the reversal beside the marking -- u0 > 0, and the cluster kernel, which is
+        //  compiled without this path: there the reversal is off the chain.)
+        if (g.u0 == 0 && h >= 1 && h <= 31) {   // (uniform)
+            const int lsh = h <= 15 ? 2 : 1;    // log2 of the lanes per swap
+            int dxy = -1, de = -1;              // position whose coordinates / edge this lane writes
+            float vx = 0.f, vy = 0.f, ve = 0.f;
+            uint16_t tv = 0;
+            if (tid < 64) {
+                const int k = tid >> lsh, q = tid & ((1 << lsh) - 1);
+                if (k < h) {
+                    int p = lo0 + k, p2 = lo0 + len - 1 - k;
+                    p -= p >= n ? n : 0;
+                    p2 -= p2 >= n ? n : 0;
+                    const int p2m = p2 == 0 ? n - 1 : p2 - 1;           // the edge in front of p2
+                    const bool side = (q & 1) != 0;                     // false: writes at p, true: at p2 / p2m
+                    if (lsh == 1 || q < 2) {
+                        const int ss = slot<Q>(side ? p : p2);
+                        dxy = side ? p2 : p;
+                        vx = v.Xq[ss].x; vy = v.Yq[ss].x;
+                        tv = v.tour[side ? p : p2];
+                    }
+                    if ((lsh == 1 || q >= 2) && k < he) {
+                        de = side ? p2m : p;
+                        ve = v.Eq[slot<Q>(side ? p : p2m)].x;
+                    }
+                } else if (tid < (h << lsh) + 2) {      // the two new boundary edges (the ends' neighbours outside)
+                    int p = lo0, p2 = lo0 + len - 1;
+                    p2 -= p2 >= n ? n : 0;
+                    const int pl = p == 0 ? n - 1 : p - 1, pr = p2 == n - 1 ? 0 : p2 + 1;
+                    const bool left = tid == (h << lsh);
+                    const int sa = slot<Q>(left ? pl : p), sb = slot<Q>(left ? p2 : pr);
+                    const float x1 = v.Xq[sa].x, y1 = v.Yq[sa].x, x2 = v.Xq[sb].x, y2 = v.Yq[sb].x;
+                    ve = dist32(x1, y1, x2, y2);        // (pl, new p = old p2) or (new p2 = old p, pr)
+                    de = left ? pl : p2;
+                }
+            }
+            if (dxy >= 0) {
+                v.tour[dxy] = tv;
+                put_xy<Q>(v, g, dxy, vx, vy);
+            }
+            if (de >= 0) put_e<Q>(v, g, de, ve);
+            FINE(pf, 8);
+            return;
+        }
+    }
     for (int k = tid; k < h; k += g.nt) {
         int p = lo0 + k, p2 = lo0 + len - 1 - k;
         p -= p >= n ? n : 0;
@@ -1580,7 +1633,7 @@ __global__ void __launch_bounds__(kMaxThreads<Q>) k_two_opt(Params p)
             FINE_START_G(pf, 0x0501);
             int lo0, len;
             resolve_move<Q>(v, n, idx, lo0, len);               // which side of the cycle; frame update
-            apply_move<T, Q>(v, g, tid, lo0, len, pf);          // phase A
+            apply_move<T, Q, !CL>(v, g, tid, lo0, len, pf);     // phase A
             if constexpr (Q != 0) {
                 if (cached) mark_touched<CL>(v, g, tid, lo0, len);
             }
