@@ -316,7 +316,7 @@ int tsp2opt_debug_cluster_inc(int32_t on);
  * one-workgroup kernel's request (lowers the workgroups resident per CU: occupancy sweeps; default 0);
  * what = 6: 1 replays coupled calls (group_size > 1) entirely in the lock-step kernel (tests; default 0);
  * what = 7: band cluster kernel, log2 of the macro steps per part when a listed cache group is recomputed
- * (default 3); what = 8: 0 plans small tours without the tile cache in whole tiles per lane instead of macro-step
+ * (default 4); what = 8: 0 plans small tours without the tile cache in whole tiles per lane instead of macro-step
  * units (default 1); what = 9: 0 plans a batch of at most one tour per compute unit like a large batch instead of
  * with two to four times the threads per tour (default 1; results never depend on it: tests run both); what = 10:
  * waves without a unit in that wide geometry, 0..12 (default 4); what = 13: lanes without a unit in a workgroup of the
