@@ -51,7 +51,7 @@ struct CParams {
     int32_t* iters;
     int32_t* work_sweeps;
     int32_t* status;
-    unsigned* csync;        // per cluster `cstride` dwords: [0] arrivals, [1] abort, [16..] slots
+    unsigned* csync;        // per cluster `cstride` dwords: [1] abort, [16..] two sets of slots (cluster_exchange_w)
     int cstride;
     int64_t num_tours;
     int tpi;
@@ -670,7 +670,7 @@ __global__ void __launch_bounds__(MAXNT) k_two_opt_cluster(CParams p)
             if (wc == 0 && p.time_limit_ticks && wall_clock64() - t_start > p.time_limit_ticks)
                 myflags |= kFlagStop;
             FINE_START(pf);
-            if (!cluster_exchange(ctl, cs, g.CS, wc, epoch, tid, nt, myflags, e, idx, fl)) { aborted = true; break; }
+            if (!cluster_exchange_w(ctl, cs, g.CS, wc, epoch, tid, myflags, e, idx, fl)) { aborted = true; break; }
             ++epoch;
             FINE(pf, 11);                                                    // cluster exchange
             if (pf.on) { const unsigned long long t1 = clock64(); t_x += t1 - tb; tb = t1; }

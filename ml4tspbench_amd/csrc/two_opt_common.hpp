@@ -58,7 +58,7 @@ struct Params {
     long long time_limit_ticks;       // wall_clock64 ticks, 0 = none
     unsigned long long* stamps;       // optional phase timers (tsp2opt_debug_phase_cycles), else null
     int dbg_sweeps;                   // > 0: diagnostic, run only this many filter sweeps per tour
-    unsigned* csync;                  // CS > 1: per cluster `cstride` dwords: [0] arrivals, [1] abort, [16..] slots
+    unsigned* csync;                  // CS > 1: per cluster `cstride` dwords: [1] abort, [16..] two sets of slots (cluster_exchange_w)
     int cstride;
     int num_clusters;
     Geo g;
@@ -131,6 +131,9 @@ struct Ctl {                          // LDS control block (first bytes of dynam
     double cx, cy, sc;
     double isc;                       // 1 / sc (a power of two, exact)
     float tsc;                        // (float)(1e-6 * sc): the reference's threshold in filter units
+    double xE;                        // cluster exchange: the cluster's winner, handed from wave 0 to the other waves
+    unsigned xIdx;                    // (fields of their own: pE / pIdx may still be read by a late wave of the selection)
+    int xok, xfl;                     // ... all slots arrived (0: gave up), a workgroup raised the stop flag
 };
 
 // ------------------------------------------------------------------------------------------

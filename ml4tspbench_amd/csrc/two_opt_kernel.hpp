@@ -1247,116 +1247,75 @@ __device__ __forceinline__ void apply_move(const View<T>& v, const Geo& g, int t
 // cluster barrier + best-move exchange (several workgroups per tour, both cluster kernels)
 // ------------------------------------------------------------------------------------------
 constexpr unsigned kSpinLimit = 1u << 26;       // bounded wait (about 10 s): never hang the GPU
-constexpr int kSlotDw = 4;                      // delta lo, delta hi, index, flags
+constexpr int kSlotDw = 8;                      // three tagged 64-bit words per slot (+ one of padding)
 
-// publish this workgroup's (e, idx), wait for the cluster, reduce all slots.  Returns false on
-// abort (a workgroup of the cluster is missing: spin limit hit).
-__device__ bool cluster_exchange(Ctl* ctl, unsigned* cs, int CS, int wc, unsigned epoch, int tid,
-                                 int nt, unsigned flags_in, double& e, unsigned& idx,
-                                 unsigned& flags_out)
-{
-    if (tid == 0) {
-        unsigned* slot = cs + 16 + ((epoch & 1u) * (unsigned)CS + (unsigned)wc) * kSlotDw;
-        __hip_atomic_store(slot + 0, (unsigned)__double2loint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slot + 1, (unsigned)__double2hiint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slot + 2, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slot + 3, flags_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(cs, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned want = (unsigned)CS * (epoch + 1u);
-        unsigned spins = 0;
-        bool ok = true;
-        while (__hip_atomic_load(cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinLimit ||
-                __hip_atomic_load(cs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                __hip_atomic_store(cs + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = false;
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        ctl->ambiguous = ok ? 0 : 1;        // reused as the abort flag
-    }
-    __syncthreads();
-    const bool ok = ctl->ambiguous == 0;
-    // slot w is read by thread w (agent-scope loads: they bypass this CU's L1), then reduced
-    e = 0.0;
-    idx = kNoMove;
-    unsigned fl = 0;
-    if (ok && tid < CS) {
-        const unsigned* sl = cs + 16 + ((epoch & 1u) * (unsigned)CS + (unsigned)tid) * kSlotDw;
-        const unsigned lo = __hip_atomic_load(sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned hi = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        idx = __hip_atomic_load(sl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fl = __hip_atomic_load(sl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        e = __hiloint2double((int)hi, (int)lo);
-    }
-    wave_best(e, idx);
-    const int anyfl = __ballot(fl != 0u) != 0ull;
-    const int nw = nt >> 6, wv = tid >> 6;
-    if ((tid & 63) == 0) { ctl->pE[wv] = e; ctl->pIdx[wv] = idx; ctl->pAmb[wv] = anyfl; }
-    __syncthreads();
-    e = ctl->pE[0];
-    idx = ctl->pIdx[0];
-    int f = ctl->pAmb[0];
-    const int nwu = (CS + 63) >> 6 < nw ? (CS + 63) >> 6 : nw;      // waves that held slots
-    for (int w = 1; w < nwu; ++w) {
-        const double oe = ctl->pE[w];
-        const unsigned oi = ctl->pIdx[w];
-        f |= ctl->pAmb[w];
-        if (better(oe, oi, e, idx)) { e = oe; idx = oi; }
-    }
-    flags_out = f ? 1u : 0u;
-    __syncthreads();
-    return ok;
-}
-
-// The same exchange for the full-window cluster (CS <= 64): after the one barrier that follows the
-// wait, EVERY wave reads all CS slots itself (lane = slot) and reduces them with DPP, so all waves hold
-// the same winner without a second trip through LDS.  That barrier also separates the waves' reads of
-// the filter window (move selection) from the writes of the reversal that follows.
+// The exchange of one iteration: publish this workgroup's (e, idx, flags), wait until every workgroup of the cluster
+// has published its own, reduce all of them (the same lexicographic rule everywhere, so all workgroups and all waves
+// arrive at the same move).  Returns false on abort (a workgroup of the cluster is missing: spin limit hit), uniformly
+// for the whole workgroup.
+//
+// Every 64-bit word of a slot carries the exchange's number in its upper half (epoch + 1: the area starts zeroed,
+// and a cluster's exchanges are numbered through all of its tours): delta low half, delta high half, index (+ the stop
+// flag in the tag's top bit).  A word is written by ONE 64-bit store and read by one 64-bit load, so a reader that sees
+// the tag sees the value: no release / acquire pair, no arrival counter -- publishing is three stores that nobody
+// waits for, and the wait is a poll of the slots themselves by wave 0 (lane = slot; agent-scope loads bypass the
+// CU's vector cache), which reduces them and hands the winner to the other waves through LDS at the barrier.
+// (Measured at TSP-1000 x 128: every wave polling for itself 13.8 -> 14.8 ms, wave 0 alone 13.5 -> 12.7 ms.)  The counter scheme it replaces cost four trips to the L2 per exchange (data, release + counter
+// increment, the poll that sees the count, the slots) where this costs two.  Slots alternate between two sets by the
+// exchange's parity: nobody can be two exchanges ahead of a workgroup that has not read the previous one.
+// The one barrier inside also separates the waves' reads of the filter window (move selection) from the writes of
+// the reversal that follows.  CS <= 64.
 __device__ bool cluster_exchange_w(Ctl* ctl, unsigned* cs, int CS, int wc, unsigned epoch, int tid,
                                    unsigned flags_in, double& e, unsigned& idx, unsigned& flags_out)
 {
+    const unsigned ep = epoch + 1u;
+    unsigned long long* set = reinterpret_cast<unsigned long long*>(cs + 16) +
+                              (size_t)((epoch & 1u) * (unsigned)CS) * (kSlotDw / 2);
     if (tid == 0) {
-        unsigned* slot = cs + 16 + ((epoch & 1u) * (unsigned)CS + (unsigned)wc) * kSlotDw;
-        __hip_atomic_store(slot + 0, (unsigned)__double2loint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slot + 1, (unsigned)__double2hiint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slot + 2, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slot + 3, flags_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(cs, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned want = (unsigned)CS * (epoch + 1u);
-        unsigned spins = 0;
+        unsigned long long* s = set + (size_t)wc * (kSlotDw / 2);
+        const unsigned long long tag = (unsigned long long)ep << 32;
+        __hip_atomic_store(s + 0, tag | (unsigned)__double2loint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(s + 1, tag | (unsigned)__double2hiint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(s + 2, ((unsigned long long)(ep | (flags_in ? 0x80000000u : 0u)) << 32) | idx,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // wave 0 polls (lane = slot), reduces and hands the result to the other waves through LDS
+    const int lane = tid & 63;
+    if (tid < 64) {
+        const unsigned long long* s = set + (size_t)(lane < CS ? lane : 0) * (kSlotDw / 2);
+        unsigned long long w0 = 0, w1 = 0, w2 = 0;
         bool ok = true;
-        while (__hip_atomic_load(cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinLimit ||
-                __hip_atomic_load(cs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        for (unsigned spins = 0;; ++spins) {
+            w0 = __hip_atomic_load(s + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w1 = __hip_atomic_load(s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w2 = __hip_atomic_load(s + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool have = (unsigned)(w0 >> 32) == ep && (unsigned)(w1 >> 32) == ep &&
+                              ((unsigned)(w2 >> 32) & 0x7fffffffu) == ep;
+            if (__ballot(!have) == 0ull) break;
+            if (spins > kSpinLimit || __hip_atomic_load(cs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                 __hip_atomic_store(cs + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = false;
                 break;
             }
+            __builtin_amdgcn_s_sleep(1);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        ctl->ambiguous = ok ? 0 : 1;        // reused as the abort flag
+        double we = 0.0;
+        unsigned wi = kNoMove;
+        bool fl = false;
+        if (ok && lane < CS) {
+            we = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+            wi = (unsigned)w2;
+            fl = (w2 >> 63) != 0ull;
+        }
+        wave_best(we, wi);
+        const unsigned fo = __ballot(fl) != 0ull ? 1u : 0u;
+        if (lane == 0) { ctl->xE = we; ctl->xIdx = wi; ctl->xok = ok ? 1 : 0; ctl->xfl = (int)fo; }
     }
     __syncthreads();
-    const bool ok = ctl->ambiguous == 0;
-    const int lane = tid & 63;
-    e = 0.0;
-    idx = kNoMove;
-    unsigned fl = 0;
-    if (ok && lane < CS) {
-        const unsigned* sl = cs + 16 + ((epoch & 1u) * (unsigned)CS + (unsigned)lane) * kSlotDw;
-        const unsigned lo = __hip_atomic_load(sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned hi = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        idx = __hip_atomic_load(sl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fl = __hip_atomic_load(sl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        e = __hiloint2double((int)hi, (int)lo);
-    }
-    wave_best(e, idx);
-    flags_out = __ballot(fl != 0u) != 0ull ? 1u : 0u;
-    return ok;
+    e = ctl->xE;
+    idx = ctl->xIdx;
+    flags_out = (unsigned)ctl->xfl;
+    return ctl->xok != 0;
 }
 
 constexpr unsigned kFlagStop = 1u;      // published by workgroup 0: wall-clock limit reached
