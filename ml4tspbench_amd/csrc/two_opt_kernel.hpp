@@ -287,11 +287,11 @@ __device__ __forceinline__ void sweep(const View<T>& v, const Geo& g, int tid,
 //      touched tile ids are compacted into a list;
 //   B  the listed tiles are recomputed evenly by all lanes (or, on list overflow, every lane re-walks
 //      its whole unit): Mc[tile] = value, Mu[unit] = min(Mu[unit], value) with an LDS atomic;
-//   C  EVERY WAVE, redundantly and without talking to the others: scan Mu for the workgroup minimum m,
-//      list the units and then the tiles inside the window m + 2 eps, re-evaluate those tiles pair by
+//   C  ONE wave (it rotates; in a cluster every wave, redundantly): scan Mu for the workgroup minimum m,
+//      find the units and then the tiles inside the window m + 2 eps, re-evaluate those tiles pair by
 //      pair in fp32 and decide (unique far-enough pair: certain move / window above the threshold:
-//      converged / else the exact stage, cooperatively).  All waves read the same LDS words and run
-//      the same deterministic instructions, so they reach the same decision with no exchange.
+//      converged / else the exact stage, cooperatively); the verdict reaches the other waves through LDS
+//      at the phase's barrier (select_cached).
 // Mu holds order-preserving unsigned keys of the float minima so that ds_min_u32 can merge them.
 __device__ __forceinline__ unsigned fkey(float f)
 {
